@@ -1,0 +1,238 @@
+"""Parameter inventory, synthetic weights and checkpoint loading for the hot path.
+
+No checkpoint ships with the reference, so parity and perf runs use
+seeded synthetic weights of the real architecture; a real diffusers-dir checkpoint
+(``unet/diffusion_pytorch_model.safetensors`` + ``vae/...``; layout per
+backends/base.py:44-58, backends/cuda_worker.py:66-77) loads through the same names.
+
+State dicts use the diffusers parameter names; values are fp16 (the precision the reference
+runs at, CUDA_DTYPE default fp16 -- backends/cuda_worker.py:55-61).
+"""
+from __future__ import annotations
+
+import json
+import os
+
+import torch
+
+from .config import unet_config, vae_config
+
+# kind: conv (OIHW), lin (out,in), vec (bias / norm affine)
+
+
+def _resnet(p, cin, cout, temb):
+    yield p + ".norm1.weight", (cin,), "gamma"
+    yield p + ".norm1.bias", (cin,), "beta"
+    yield p + ".conv1.weight", (cout, cin, 3, 3), "w"
+    yield p + ".conv1.bias", (cout,), "bias"
+    if temb:
+        yield p + ".time_emb_proj.weight", (cout, temb), "w"
+        yield p + ".time_emb_proj.bias", (cout,), "bias"
+    yield p + ".norm2.weight", (cout,), "gamma"
+    yield p + ".norm2.bias", (cout,), "beta"
+    yield p + ".conv2.weight", (cout, cout, 3, 3), "w_res"
+    yield p + ".conv2.bias", (cout,), "bias"
+    if cin != cout:
+        yield p + ".conv_shortcut.weight", (cout, cin, 1, 1), "w"
+        yield p + ".conv_shortcut.bias", (cout,), "bias"
+
+
+def _transformer(p, c, ctx):
+    yield p + ".norm.weight", (c,), "gamma"
+    yield p + ".norm.bias", (c,), "beta"
+    yield p + ".proj_in.weight", (c, c, 1, 1), "w"
+    yield p + ".proj_in.bias", (c,), "bias"
+    t = p + ".transformer_blocks.0"
+    for n in ("norm1", "norm2", "norm3"):
+        yield f"{t}.{n}.weight", (c,), "gamma"
+        yield f"{t}.{n}.bias", (c,), "beta"
+    for a, kdim in (("attn1", c), ("attn2", ctx)):
+        yield f"{t}.{a}.to_q.weight", (c, c), "w"
+        yield f"{t}.{a}.to_k.weight", (c, kdim), "w"
+        yield f"{t}.{a}.to_v.weight", (c, kdim), "w"
+        yield f"{t}.{a}.to_out.0.weight", (c, c), "w_res"
+        yield f"{t}.{a}.to_out.0.bias", (c,), "bias"
+    yield f"{t}.ff.net.0.proj.weight", (8 * c, c), "w"
+    yield f"{t}.ff.net.0.proj.bias", (8 * c,), "bias"
+    yield f"{t}.ff.net.2.weight", (c, 4 * c), "w_res"
+    yield f"{t}.ff.net.2.bias", (c,), "bias"
+    yield p + ".proj_out.weight", (c, c, 1, 1), "w_res"
+    yield p + ".proj_out.bias", (c,), "bias"
+
+
+def unet_param_spec(cfg: dict | None = None):
+    cfg = unet_config(cfg)
+    boc = cfg["block_out_channels"]
+    temb = boc[0] * 4
+    ctx = cfg["cross_attention_dim"]
+    yield "conv_in.weight", (boc[0], cfg["in_channels"], 3, 3), "w"
+    yield "conv_in.bias", (boc[0],), "bias"
+    yield "time_embedding.linear_1.weight", (temb, boc[0]), "w"
+    yield "time_embedding.linear_1.bias", (temb,), "bias"
+    yield "time_embedding.linear_2.weight", (temb, temb), "w"
+    yield "time_embedding.linear_2.bias", (temb,), "bias"
+    if cfg.get("time_cond_proj_dim"):
+        yield "time_embedding.cond_proj.weight", (boc[0], cfg["time_cond_proj_dim"]), "w"
+    nb = len(boc)
+    skip_ch = [boc[0]]
+    ch = boc[0]
+    for i in range(nb):
+        for j in range(cfg["layers_per_block"]):
+            yield from _resnet(f"down_blocks.{i}.resnets.{j}", ch, boc[i], temb)
+            ch = boc[i]
+            if cfg["down_attn"][i]:
+                yield from _transformer(f"down_blocks.{i}.attentions.{j}", ch, ctx)
+            skip_ch.append(ch)
+        if i < nb - 1:
+            yield f"down_blocks.{i}.downsamplers.0.conv.weight", (ch, ch, 3, 3), "w"
+            yield f"down_blocks.{i}.downsamplers.0.conv.bias", (ch,), "bias"
+            skip_ch.append(ch)
+    yield from _resnet("mid_block.resnets.0", ch, ch, temb)
+    yield from _transformer("mid_block.attentions.0", ch, ctx)
+    yield from _resnet("mid_block.resnets.1", ch, ch, temb)
+    rboc = tuple(reversed(boc))
+    up_attn = tuple(reversed(cfg["down_attn"]))
+    for i in range(nb):
+        for j in range(cfg["layers_per_block"] + 1):
+            s = skip_ch.pop()
+            yield from _resnet(f"up_blocks.{i}.resnets.{j}", ch + s, rboc[i], temb)
+            ch = rboc[i]
+            if up_attn[i]:
+                yield from _transformer(f"up_blocks.{i}.attentions.{j}", ch, ctx)
+        if i < nb - 1:
+            yield f"up_blocks.{i}.upsamplers.0.conv.weight", (ch, ch, 3, 3), "w"
+            yield f"up_blocks.{i}.upsamplers.0.conv.bias", (ch,), "bias"
+    yield "conv_norm_out.weight", (ch,), "gamma"
+    yield "conv_norm_out.bias", (ch,), "beta"
+    yield "conv_out.weight", (cfg["out_channels"], ch, 3, 3), "w_out"
+    yield "conv_out.bias", (cfg["out_channels"],), "bias"
+
+
+def vae_param_spec(cfg: dict | None = None):
+    cfg = vae_config(cfg)
+    boc = cfg["block_out_channels"]
+    lc = cfg["latent_channels"]
+    yield "post_quant_conv.weight", (lc, lc, 1, 1), "w"
+    yield "post_quant_conv.bias", (lc,), "bias"
+    top = boc[-1]
+    yield "decoder.conv_in.weight", (top, lc, 3, 3), "w"
+    yield "decoder.conv_in.bias", (top,), "bias"
+    yield from _resnet("decoder.mid_block.resnets.0", top, top, 0)
+    a = "decoder.mid_block.attentions.0"
+    yield a + ".group_norm.weight", (top,), "gamma"
+    yield a + ".group_norm.bias", (top,), "beta"
+    for n in ("to_q", "to_k", "to_v"):
+        yield f"{a}.{n}.weight", (top, top), "w"
+        yield f"{a}.{n}.bias", (top,), "bias"
+    yield a + ".to_out.0.weight", (top, top), "w_res"
+    yield a + ".to_out.0.bias", (top,), "bias"
+    yield from _resnet("decoder.mid_block.resnets.1", top, top, 0)
+    ch = top
+    rboc = tuple(reversed(boc))
+    nb = len(boc)
+    for i in range(nb):
+        for j in range(cfg["layers_per_block"] + 1):
+            yield from _resnet(f"decoder.up_blocks.{i}.resnets.{j}", ch, rboc[i], 0)
+            ch = rboc[i]
+        if i < nb - 1:
+            yield f"decoder.up_blocks.{i}.upsamplers.0.conv.weight", (ch, ch, 3, 3), "w"
+            yield f"decoder.up_blocks.{i}.upsamplers.0.conv.bias", (ch,), "bias"
+    yield "decoder.conv_norm_out.weight", (ch,), "gamma"
+    yield "decoder.conv_norm_out.bias", (ch,), "beta"
+    yield "decoder.conv_out.weight", (cfg["out_channels"], ch, 3, 3), "w_out"
+    yield "decoder.conv_out.bias", (cfg["out_channels"],), "bias"
+
+
+def count_params(spec) -> int:
+    n = 0
+    for _, shape, _ in spec:
+        k = 1
+        for s in shape:
+            k *= s
+        n += k
+    return n
+
+
+def synthetic_state_dict(spec, seed: int, res_scale: float = 0.25) -> dict:
+    """Seeded, variance-preserving weights stored as fp16.
+
+    w: N(0, 1/fan_in); residual-branch output layers additionally x ``res_scale`` so the
+    4-step feedback loop stays well-conditioned; norm gamma ~ 1 +- 0.1, beta ~ +-0.1.
+    """
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    sd = {}
+    for name, shape, kind in spec:
+        if kind in ("w", "w_res", "w_out"):
+            fan_in = 1
+            for s in shape[1:]:
+                fan_in *= s
+            std = fan_in ** -0.5
+            if kind == "w_res":
+                std *= res_scale
+            t = torch.randn(shape, generator=g, dtype=torch.float32) * std
+        elif kind == "gamma":
+            t = 1.0 + 0.1 * torch.randn(shape, generator=g, dtype=torch.float32)
+        elif kind == "beta":
+            t = 0.1 * torch.randn(shape, generator=g, dtype=torch.float32)
+        else:  # bias
+            t = 0.02 * torch.randn(shape, generator=g, dtype=torch.float32)
+        sd[name] = t.to(torch.float16)
+    return sd
+
+
+def synthetic_unet(cfg=None, seed=0):
+    return synthetic_state_dict(unet_param_spec(cfg), seed)
+
+
+def synthetic_vae(cfg=None, seed=1):
+    return synthetic_state_dict(vae_param_spec(cfg), seed)
+
+
+# ---------------------------------------------------------------------------------------
+# real checkpoints (diffusers directory layout)
+# ---------------------------------------------------------------------------------------
+def _load_safetensors_dir(d: str) -> dict:
+    from safetensors.torch import load_file
+    for fn in ("diffusion_pytorch_model.fp16.safetensors", "diffusion_pytorch_model.safetensors"):
+        p = os.path.join(d, fn)
+        if os.path.exists(p):
+            return {k: v.to(torch.float16) for k, v in load_file(p).items()}
+    raise FileNotFoundError(f"no diffusion_pytorch_model*.safetensors under {d}")
+
+
+def load_diffusers_dir(root: str):
+    """-> (unet_sd, unet_cfg, vae_sd, vae_cfg) from a diffusers-layout checkpoint directory."""
+    def cfg_of(sub, base):
+        with open(os.path.join(root, sub, "config.json")) as f:
+            j = json.load(f)
+        out = dict(base)
+        for k in base:
+            if k in j and j[k] is not None:
+                out[k] = tuple(j[k]) if isinstance(j[k], list) else j[k]
+        return j, out
+
+    ju, ucfg = cfg_of("unet", unet_config())
+    ucfg["time_cond_proj_dim"] = ju.get("time_cond_proj_dim")
+    if "down_block_types" in ju:
+        ucfg["down_attn"] = tuple("CrossAttn" in t for t in ju["down_block_types"])
+    _, vcfg = cfg_of("vae", vae_config())
+    usd = _load_safetensors_dir(os.path.join(root, "unet"))
+    vsd = _load_safetensors_dir(os.path.join(root, "vae"))
+    vsd = {k: v for k, v in vsd.items() if k.startswith("decoder.") or k.startswith("post_quant_conv.")}
+    # older VAE checkpoints name the mid attention query/key/value/proj_attn
+    ren = {"query": "to_q", "key": "to_k", "value": "to_v", "proj_attn": "to_out.0"}
+    for k in list(vsd):
+        for old, new in ren.items():
+            tag = f".attentions.0.{old}."
+            if tag in k:
+                vsd[k.replace(tag, f".attentions.0.{new}.")] = vsd.pop(k)
+    for name, shape, _ in list(unet_param_spec(ucfg)) :
+        if name not in usd or tuple(usd[name].shape) != tuple(shape):
+            raise RuntimeError(f"checkpoint/graph mismatch at unet '{name}': expected {shape}, "
+                               f"got {tuple(usd[name].shape) if name in usd else None}")
+    for name, shape, _ in list(vae_param_spec(vcfg)):
+        if name not in vsd:
+            raise RuntimeError(f"checkpoint/graph mismatch at vae '{name}'")
+        if tuple(vsd[name].shape) != tuple(shape):
+            vsd[name] = vsd[name].reshape(shape)   # linear attn stored as 1x1 conv or vice versa
+    return usd, ucfg, vsd, vcfg
