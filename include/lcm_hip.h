@@ -1,0 +1,129 @@
+/*
+ * lcm_hip.h -- C ABI of the MI355X (gfx950) LCM Stable-Diffusion-1.5 hot path.
+ *
+ * The reference has no FFI of its own: its hot path is one Python call,
+ *   self.pipe(prompt=..., width=..., height=..., num_inference_steps=..., guidance_scale=..., generator=...)
+ * at backends/cuda_worker.py:221-229 (diffusers StableDiffusionPipeline + LCMScheduler), behind the
+ * PipelineWorker Protocol of backends/base.py:29-39.  This header is the boundary a maintainer binds
+ * (ctypes stub in INTEGRATION.md) to replace the arithmetic under that call.  Each entry point names the
+ * operator of the reference's op graph it replaces (diffusers module, reached from the call site above;
+ * numpy twin of the glue in backends/rknnlcm.py where one exists).
+ *
+ * Conventions
+ *   - all device pointers; activations are fp16 "pixel-major" (NHWC == [B*H*W, C] row major) unless stated;
+ *     latents / noise / eps-state are fp32 NCHW (the request-side layout of backends/rknnlcm.py:424).
+ *   - weights are fp16, row = output channel, k-contiguous; 3x3 weights are [Cout][ky][kx][Cin].
+ *   - every function enqueues on `stream` (hipStream_t passed as void*), never synchronises, and
+ *     returns 0 on success or a negative LCM_E* / positive hipError_t code; lcm_last_error() gives text.
+ *   - nothing here allocates: callers own all buffers (graph-capture safe).
+ */
+#ifndef LCM_HIP_H
+#define LCM_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LCM_OK 0
+#define LCM_EINVAL (-1)   /* shape / alignment precondition violated */
+#define LCM_ENODEV (-2)   /* no gfx950 device */
+
+#define LCM_EPI_NONE 0
+#define LCM_EPI_GEGLU 1   /* out[m][j] = x*gelu(g); weight rows interleaved x/g in blocks of 16 */
+
+const char* lcm_last_error(void);
+int lcm_version(void);
+/* device_count / arch string of device `dev` (buf >= 64 bytes) */
+int lcm_device_info(int dev, char* arch_buf, int buf_len, int* cu_count, uint64_t* hbm_bytes);
+
+/* ---- dense contraction (torch.nn.Linear / 1x1 Conv2d inside UNet2DConditionModel, AutoencoderKL) ----
+ * out[z][m][n] = out_scale * sum_k A[z][m][k] * W[z][n][k]  (+bias[n]) (+rowadd[m / rows_per_batch][n]) (+res[m][n])
+ * A may be split along k over two sources (fused torch.cat of the up-block skip: k < K1 from A, else A2).
+ * Preconditions: K % 64 == 0, K1 % 64 == 0, N % 64 == 0 (N % 32 for GEGLU pairs), 16-byte aligned rows.
+ */
+int lcm_gemm_f16(const void* A, int lda, const void* A2, int lda2, int K1,
+                 const void* W, const void* bias, const void* rowadd, int ld_rowadd, int rows_per_batch,
+                 const void* res, int ldr, void* out, int ldo,
+                 int M, int N, int K, int epilogue, float out_scale,
+                 int batch, int64_t strideA, int64_t strideW, int64_t strideO, void* stream);
+
+/* ---- 3x3 convolution, padding 1 (ResnetBlock2D.conv1/conv2, Downsample2D, Upsample2D.conv) ----
+ * implicit GEMM over K = 9*Cin on MFMA; in: [B,Hin,Win,Cin]; stride 1|2; ups=1 reads the input through a
+ * nearest-2x upsample (F.interpolate(scale_factor=2) fused into the loader).  Epilogue as lcm_gemm_f16.
+ * Preconditions: Cin % 64 == 0, Cout % 64 == 0.
+ */
+int lcm_conv3x3_f16(const void* in, const void* W, const void* bias,
+                    const void* rowadd, int ld_rowadd, const void* res, void* out,
+                    int B, int Hin, int Win, int Cin, int Cout, int stride, int ups, void* stream);
+
+/* ---- 3x3 convolution from the fp32 NCHW latent (UNet conv_in; VAE post_quant_conv+decoder.conv_in) ----
+ * in: fp32 [B,4,H,W]; optional pre-transform z = pre_w(4x4 fp32, row=out) * (in * in_scale) + pre_b
+ * (AutoencoderKL: latents / scaling_factor -> post_quant_conv, backends/rknnlcm.py:614).
+ * W: fp16 [Cout][9][4]; out: fp16 [B,H,W,Cout].  Cout % 8 == 0.
+ */
+int lcm_conv3x3_c4_f32in(const void* in, const void* pre_w, const void* pre_b, float in_scale,
+                         const void* W, const void* bias, void* out, int B, int H, int Wd, int Cout, void* stream);
+
+/* ---- 3x3 convolution to a few channels (UNet conv_out -> eps; VAE decoder.conv_out -> RGB) ----
+ * in: fp16 [B,H,W,Cin], W: fp16 [Cout][9][Cin], Cout <= 4, Cin % 8 == 0.
+ * mode 0: out fp32 [B,H,W,Cout];  mode 1: out u8 [B,H,W,Cout] = rint(clamp(y/2+0.5,0,1)*255)
+ * (VaeImageProcessor.postprocess; backends/rknnlcm.py:223,232-236,259); out_f32 optional float copy (NHWC).
+ */
+int lcm_conv3x3_smalln(const void* in, const void* W, const void* bias, void* out, void* out_f32,
+                       int B, int H, int Wd, int Cin, int Cout, int mode, void* stream);
+
+/* ---- GroupNorm (+SiLU) over [B,HW,C1(+C2)] (ResnetBlock2D.norm1/2, Transformer2DModel.norm, conv_norm_out) ----
+ * x2 != NULL normalises the channel concatenation [x | x2] (fused torch.cat of the skip) and writes the
+ * concatenated tensor.  ws: fp32 workspace of lcm_groupnorm_ws_bytes().  Deterministic (no atomics).
+ */
+int64_t lcm_groupnorm_ws_bytes(int B, int HW, int C, int groups);
+int lcm_groupnorm_f16(const void* x, int C1, const void* x2, int C2, const void* gamma, const void* beta,
+                      void* out, int B, int HW, int groups, float eps, int silu, void* ws, void* stream);
+
+/* ---- LayerNorm over the last dim (BasicTransformerBlock.norm1/2/3) ---- */
+int lcm_layernorm_f16(const void* x, const void* gamma, const void* beta, void* out, int M, int C, float eps,
+                      void* stream);
+
+/* ---- fused attention softmax(scale*Q K^T) V (Attention in BasicTransformerBlock.attn1/attn2) ----
+ * Q: rows b*Sq+s, element (h*d + i) at Q[row*ldq + ...]; K,V likewise with Sk rows per batch; out [B*Sq][ldo].
+ * d % 8 == 0, d <= 160.  Online softmax in fp32, no S x S matrix in memory.
+ */
+int lcm_attention_f16(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* out, int ldo,
+                      int B, int heads, int Sq, int Sk, int d, float scale, void* stream);
+
+/* ---- row softmax in place over [rows][n] fp16 (AutoencoderKL mid-block attention, d=512 single head) ---- */
+int lcm_softmax_rows_f16(void* x, int rows, int n, int ld, void* stream);
+/* ---- [z][R][C] -> [z][C][R] transpose, fp16 ---- */
+int lcm_transpose_f16(const void* in, int ldi, void* out, int ldo, int R, int C, int batch,
+                      int64_t stride_in, int64_t stride_out, void* stream);
+
+/* ---- small-M linear (TimestepEmbedding, ResnetBlock2D.time_emb_proj): M <= 16 ----
+ * out[m][n] = act_out( sum_k act_in(x[m][k]) W[n][k] + bias[n] + res[m][n] ), act = SiLU when flagged.
+ */
+int lcm_linear_smallm_f16(const void* x, int ldx, const void* W, const void* bias, const void* res, int ldr,
+                          void* out, int ldo, int M, int N, int K, int silu_in, int silu_out, void* stream);
+
+/* ---- Timesteps(flip_sin_to_cos=True, freq_shift=0): out fp16 [B][dim] = [cos | sin](t * f) ---- */
+int lcm_timestep_embedding(float t, void* out, int B, int dim, void* stream);
+
+/* ---- LCMScheduler.step (backends/rknnlcm.py:596-599), epsilon prediction, fp32 state ----
+ * eps: fp32 NHWC [B,h,w,4] (conv_out); eps_uncond != NULL applies classifier-free guidance first.
+ * lat (in/out): fp32 NCHW [B,4,h,w]; noise fp32 NCHW (ignored when last).  coef = {sqrt_alpha_t, sqrt_beta_t,
+ * c_skip, c_out, sqrt_alpha_prev, sqrt_beta_prev}.
+ */
+int lcm_scheduler_step(const void* eps, const void* eps_uncond, float guidance, void* lat, const void* noise,
+                       const float* coef6, int last, int B, int h, int w, void* stream);
+
+/* ---- adaptive_avg_pool2d(lat,(8,8)) -> fp16 [B,4,8,8] (run_job_with_latents, backends/cuda_worker.py:299-304) */
+int lcm_latents_pool8(const void* lat, void* out_f16, int B, int h, int w, void* stream);
+
+/* ---- hipGraph capture of the 4-step sampler loop + VAE ---- */
+int lcm_graph_begin(void* stream);
+int lcm_graph_end(void* stream, void** graph_exec_out);
+int lcm_graph_launch(void* graph_exec, void* stream);
+int lcm_graph_destroy(void* graph_exec);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

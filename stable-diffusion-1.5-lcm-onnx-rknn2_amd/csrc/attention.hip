@@ -1,0 +1,229 @@
+// Fused attention softmax(scale * Q K^T) V for gfx950 -- flash-style, no S x S matrix in memory.
+//
+// Replaces diffusers Attention (attn1 self / attn2 cross) inside BasicTransformerBlock of
+// UNet2DConditionModel, reached from backends/cuda_worker.py:221-229.  SD1.5 shapes: 8 heads,
+// head_dim 40/80/160, Sq = H*W in {4096,1024,256,64,...}, Sk = Sq (self) or 77 (cross).
+//
+// Structure (one workgroup = 4 waves = 128 query rows of one (batch, head); 64-key K/V tiles in LDS):
+//   * "swapped" QK^T: S^T = K Q^T with mfma_f32_32x32x16_f16 (A = K rows from LDS via ds_read_b128,
+//     B = Q rows held in registers), so each lane owns ONE query column: the online-softmax running
+//     max / sum / rescale are per-lane scalars (one __shfl_xor(.,32) joins the two lane halves).
+//   * the S^T accumulator registers 8s..8s+7, converted to fp16, ARE the B operand of the second MFMA
+//     (O^T = V^T P^T), k-slot (half h, element j) <-> key 16s + 8(j>>2) + 4h + (j&3); no LDS round trip.
+//   * V stays row-major in LDS ([key][d], coalesced from HBM); the V^T A-fragments come from two
+//     ds_read_b64_tr_b16 (hardware transpose) per fragment; row strides are chosen conflict-free.
+//   * K/V tiles are register-staged one tile ahead (loads issued before the MFMAs of the current tile).
+#include "common.h"
+
+struct AttnParams {
+    const half_t* Q; const half_t* K; const half_t* V; half_t* O;
+    int ldq, ldk, ldv, ldo;
+    int B, heads, Sq, Sk;
+    float sc;   // scale * log2(e)
+};
+
+template <int D>
+struct AttnCfg {
+    static constexpr int DK = (D + 15) / 16 * 16;     // k extent of QK^T (mfma K = 16)
+    static constexpr int DV = (D + 31) / 32 * 32;     // row extent of O^T (mfma M = 32)
+    static constexpr int KS = DK * 2 + 16;            // K row stride bytes: 16 * odd -> b128 conflict-free
+    static constexpr int VS0 = DV * 2;
+    static constexpr int VS = ((VS0 % 256) == 64 || (VS0 % 256) == 192) ? VS0 : VS0 + 64;  // tr_b16 conflict-free
+    static constexpr int NCH = D / 8;                 // 16-byte chunks per row
+    static constexpr int NLD = (64 * NCH + 255) / 256;  // staged chunks per thread per tensor
+    static constexpr int LDS_BYTES = 64 * KS + 64 * VS;
+};
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
+    using C = AttnCfg<D>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;
+    char* Vs = smem + 64 * C::KS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int bh = blockIdx.y, b = bh / p.heads, head = bh - b * p.heads;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int qrow = q0 + l31;
+
+    const half_t* Qb = p.Q + (long long)b * p.Sq * p.ldq + head * D;
+    const half_t* Kb = p.K + (long long)b * p.Sk * p.ldk + head * D;
+    const half_t* Vb = p.V + (long long)b * p.Sk * p.ldv + head * D;
+
+    // zero LDS once: pad columns (d >= D) must read as 0
+    for (int i = tid * 16; i < C::LDS_BYTES; i += 256 * 16) *reinterpret_cast<f4*>(smem + i) = (f4){0.f, 0.f, 0.f, 0.f};
+
+    // Q fragments (B operand): lane holds Q[qrow][16ks + 8hh + j]
+    h8 qf[C::DK / 16];
+#pragma unroll
+    for (int ks = 0; ks < C::DK / 16; ++ks) {
+        const int dc = 16 * ks + 8 * hh;
+        h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (qrow < p.Sq && dc < D) v = *reinterpret_cast<const h8*>(Qb + (long long)qrow * p.ldq + dc);
+        qf[ks] = v;
+    }
+
+    h8 rk[C::NLD], rv[C::NLD];
+    auto load_tile = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < C::NLD; ++i) {
+            const int idx = tid + 256 * i;
+            h8 a = {0, 0, 0, 0, 0, 0, 0, 0}, c = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (idx < 64 * C::NCH) {
+                const int r = idx / C::NCH, ch = idx - r * C::NCH;
+                const int key = t * 64 + r;
+                if (key < p.Sk) {
+                    a = *reinterpret_cast<const h8*>(Kb + (long long)key * p.ldk + ch * 8);
+                    c = *reinterpret_cast<const h8*>(Vb + (long long)key * p.ldv + ch * 8);
+                }
+            }
+            rk[i] = a; rv[i] = c;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < C::NLD; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < 64 * C::NCH) {
+                const int r = idx / C::NCH, ch = idx - r * C::NCH;
+                *reinterpret_cast<h8*>(Ks + r * C::KS + ch * 16) = rk[i];
+                *reinterpret_cast<h8*>(Vs + r * C::VS + ch * 16) = rv[i];
+            }
+        }
+    };
+
+    f16v oacc[C::DV / 32];
+#pragma unroll
+    for (int i = 0; i < C::DV / 32; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+    float m_run = -1.0e30f, l_run = 0.f;
+
+    const int ntiles = (p.Sk + 63) / 64;
+    load_tile(0);
+    // per-lane LDS addresses
+    const int k_addr = l31 * C::KS + 16 * hh;                                  // + kb*32*KS + ks*32
+    const int v_addr = (4 * hh + ((lane & 15) >> 2)) * C::VS + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+
+    for (int t = 0; t < ntiles; ++t) {
+        __syncthreads();          // everyone done reading the previous tile (and the zero fill)
+        store_tile();
+        __syncthreads();
+        if (t + 1 < ntiles) load_tile(t + 1);
+
+        // ---- S^T = K Q^T ----
+        f16v sacc[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < C::DK / 16; ++ks) {
+                h8 kf = *reinterpret_cast<const h8*>(Ks + k_addr + kb * 32 * C::KS + ks * 32);
+                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], sacc[kb], 0, 0, 0);
+            }
+        }
+        // ---- online softmax (per-lane query column) ----
+        if (t * 64 + 64 > p.Sk) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = t * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    if (key >= p.Sk) sacc[kb][r] = -1.0e30f;
+                }
+        }
+        float mt = -1.0e30f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mt = fmaxf(mt, sacc[kb][r]);
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        const float m_new = fmaxf(m_run, mt * p.sc);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.f;
+        h8 pf[2][2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = __builtin_amdgcn_exp2f(sacc[kb][r] * p.sc - m_new);
+                psum += pv;
+                pf[kb][r >> 3][r & 7] = (half_t)pv;
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int i = 0; i < C::DV / 32; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+
+        // ---- O^T += V^T P^T ----
+#pragma unroll
+        for (int db = 0; db < C::DV / 32; ++db) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const char* base = Vs + v_addr + (kb * 32 + 16 * s) * C::VS + db * 64;
+                    s4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4 __attribute__((address_space(3)))*)(base));
+                    s4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (s4 __attribute__((address_space(3)))*)(base + 8 * C::VS));
+                    h4 lo_h = __builtin_bit_cast(h4, lo), hi_h = __builtin_bit_cast(h4, hi);
+                    h8 vf = {lo_h[0], lo_h[1], lo_h[2], lo_h[3], hi_h[0], hi_h[1], hi_h[2], hi_h[3]};
+                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kb][s], oacc[db], 0, 0, 0);
+                }
+        }
+    }
+
+    // ---- epilogue: O[q][d] = O^T[d][q] / l ----
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (qrow < p.Sq) {
+        half_t* orow = p.O + ((long long)b * p.Sq + qrow) * p.ldo + head * D;
+#pragma unroll
+        for (int db = 0; db < C::DV / 32; ++db)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int d0 = db * 32 + 8 * rq + 4 * hh;
+                if (d0 < D) {
+                    h4 o = {(half_t)(oacc[db][4 * rq] * inv), (half_t)(oacc[db][4 * rq + 1] * inv),
+                            (half_t)(oacc[db][4 * rq + 2] * inv), (half_t)(oacc[db][4 * rq + 3] * inv)};
+                    *reinterpret_cast<h4*>(orow + d0) = o;
+                }
+            }
+    }
+}
+
+template <int D>
+static int launch_attn(const AttnParams& p, hipStream_t s) {
+    using C = AttnCfg<D>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<D>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        attr_set = true;
+    }
+    dim3 grid((p.Sq + 127) / 128, p.B * p.heads);
+    hipLaunchKernelGGL((attn_kernel<D>), grid, dim3(256), C::LDS_BYTES, s, p);
+    LCM_CHECK_LAUNCH("attention");
+    return LCM_OK;
+}
+
+extern "C" int lcm_attention_f16(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* out,
+                                 int ldo, int B, int heads, int Sq, int Sk, int d, float scale, void* stream) {
+    LCM_REQUIRE(Q && K && V && out, "attention: null pointer");
+    LCM_REQUIRE(B > 0 && heads > 0 && Sq > 0 && Sk > 0, "attention: bad shape");
+    LCM_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0, "attention: misaligned leading dims");
+    AttnParams p = {(const half_t*)Q, (const half_t*)K, (const half_t*)V, (half_t*)out, ldq, ldk, ldv, ldo,
+                    B, heads, Sq, Sk, scale * 1.4426950408889634f};
+    hipStream_t s = (hipStream_t)stream;
+    switch (d) {
+        case 40: return launch_attn<40>(p, s);
+        case 64: return launch_attn<64>(p, s);
+        case 80: return launch_attn<80>(p, s);
+        case 160: return launch_attn<160>(p, s);
+        default: lcm_set_error("attention: unsupported head_dim %d (40/64/80/160)", d); return LCM_EINVAL;
+    }
+}

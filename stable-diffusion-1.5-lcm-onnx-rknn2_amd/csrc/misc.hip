@@ -1,0 +1,316 @@
+// Boundary / latency kernels of the LCM hot path on gfx950: latent-side convolutions, the time-embedding
+// MLP, the LCM scheduler step, the RGB8 epilogue, the 8x8 latent blob, a tiled transpose.
+// (UNet conv_in / conv_out, TimestepEmbedding, LCMScheduler.step, VaeImageProcessor.postprocess,
+//  reached from backends/cuda_worker.py:221-229; numpy twins backends/rknnlcm.py:596-599, :211-264.)
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------
+// conv3x3 from fp32 NCHW latents (Cin = 4) -> fp16 pixel-major [B,H,W,Cout].
+// One thread = one pixel x 8 output channels; the 36 (transformed) inputs of the pixel are gathered once
+// per thread, weights [Cout][36] live in LDS.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_c4_kernel(const float* __restrict__ in, const float* __restrict__ pre_w,
+                                                      const float* __restrict__ pre_b, float in_scale,
+                                                      const half_t* __restrict__ W, const half_t* __restrict__ bias,
+                                                      half_t* __restrict__ out, int B, int H, int Wd, int Cout) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    half_t* ws = reinterpret_cast<half_t*>(smem);           // [Cout][36]
+    for (int i = threadIdx.x; i < Cout * 36; i += 256) ws[i] = W[i];
+    __syncthreads();
+    const int ng = Cout >> 3;
+    const long long total = (long long)B * H * Wd * ng;
+    const long long plane = (long long)H * Wd;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int g = (int)(idx % ng);
+        const long long pix = idx / ng;
+        const int x = (int)(pix % Wd), y = (int)((pix / Wd) % H), b = (int)(pix / plane);
+        float v[36];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int iy = y + tap / 3 - 1, ix = x + tap % 3 - 1;
+            float z[4] = {0.f, 0.f, 0.f, 0.f};
+            if (iy >= 0 && iy < H && ix >= 0 && ix < Wd) {
+                float r[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) r[c] = in[((long long)(b * 4 + c) * H + iy) * Wd + ix] * in_scale;
+                if (pre_w) {
+#pragma unroll
+                    for (int o = 0; o < 4; ++o)
+                        z[o] = pre_b[o] + pre_w[o * 4] * r[0] + pre_w[o * 4 + 1] * r[1] + pre_w[o * 4 + 2] * r[2] +
+                               pre_w[o * 4 + 3] * r[3];
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) z[c] = r[c];
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[tap * 4 + c] = z[c];
+        }
+        h8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int co = g * 8 + j;
+            float acc = bias ? (float)bias[co] : 0.f;
+            const half_t* wr = ws + co * 36;
+#pragma unroll
+            for (int k = 0; k < 36; ++k) acc += v[k] * (float)wr[k];
+            o[j] = (half_t)acc;
+        }
+        *reinterpret_cast<h8*>(out + pix * Cout + g * 8) = o;
+    }
+}
+
+extern "C" int lcm_conv3x3_c4_f32in(const void* in, const void* pre_w, const void* pre_b, float in_scale,
+                                    const void* W, const void* bias, void* out, int B, int H, int Wd, int Cout,
+                                    void* stream) {
+    LCM_REQUIRE(in && W && out, "conv_c4: null pointer");
+    LCM_REQUIRE(B > 0 && H > 0 && Wd > 0 && Cout % 8 == 0 && Cout <= 1024, "conv_c4: bad shape");
+    LCM_REQUIRE((pre_w == nullptr) == (pre_b == nullptr), "conv_c4: pre_w/pre_b must come together");
+    const long long total = (long long)B * H * Wd * (Cout / 8);
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(conv_c4_kernel, dim3(grid), dim3(256), Cout * 36 * 2, (hipStream_t)stream, (const float*)in,
+                       (const float*)pre_w, (const float*)pre_b, in_scale, (const half_t*)W, (const half_t*)bias,
+                       (half_t*)out, B, H, Wd, Cout);
+    LCM_CHECK_LAUNCH("conv_c4");
+    return LCM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// conv3x3 to <= 4 output channels.  A pixel is shared by LPP = Cin/8 (<= 64, power of two or padded)
+// lanes, each owning 8 input channels over the 9 taps; shuffle reduction inside the lane group.
+// ---------------------------------------------------------------------------------------------
+template <int LPP>
+__global__ __launch_bounds__(256) void conv_smalln_kernel(const half_t* __restrict__ in, const half_t* __restrict__ W,
+                                                          const half_t* __restrict__ bias, void* __restrict__ out,
+                                                          float* __restrict__ out_f32, int B, int H, int Wd, int Cin,
+                                                          int Cout, int mode) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    half_t* ws = reinterpret_cast<half_t*>(smem);   // [Cout][9][Cin]
+    for (int i = threadIdx.x * 8; i < Cout * 9 * Cin; i += 256 * 8)
+        *reinterpret_cast<h8*>(ws + i) = *reinterpret_cast<const h8*>(W + i);
+    __syncthreads();
+    constexpr int PPW = 256 / LPP;                  // pixels per workgroup pass
+    const int sub = threadIdx.x % LPP, pl = threadIdx.x / LPP;
+    const int ncc = Cin >> 3;
+    const long long npix = (long long)B * H * Wd;
+    for (long long pix0 = (long long)blockIdx.x * PPW; pix0 < npix; pix0 += (long long)gridDim.x * PPW) {
+        const long long pix = pix0 + pl;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        if (pix < npix) {
+            const int x = (int)(pix % Wd), y = (int)((pix / Wd) % H), b = (int)(pix / ((long long)H * Wd));
+            for (int cc = sub; cc < ncc; cc += LPP) {
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int iy = y + tap / 3 - 1, ix = x + tap % 3 - 1;
+                    if (iy < 0 || iy >= H || ix < 0 || ix >= Wd) continue;
+                    h8 v = *reinterpret_cast<const h8*>(in + (((long long)b * H + iy) * Wd + ix) * Cin + cc * 8);
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) {
+                        if (o < Cout) {
+                            h8 w = *reinterpret_cast<const h8*>(ws + (o * 9 + tap) * Cin + cc * 8);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) acc[o] += (float)v[j] * (float)w[j];
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+#pragma unroll
+            for (int off = LPP / 2; off > 0; off >>= 1) acc[o] += __shfl_xor(acc[o], off, 64);
+        if (pix < npix && sub == 0) {
+            for (int o = 0; o < Cout; ++o) {
+                const float yv = acc[o] + (bias ? (float)bias[o] : 0.f);
+                if (out_f32) out_f32[pix * Cout + o] = yv;
+                if (mode == 0) {
+                    reinterpret_cast<float*>(out)[pix * Cout + o] = yv;
+                } else {
+                    const float u = fminf(fmaxf(yv * 0.5f + 0.5f, 0.f), 1.f);
+                    reinterpret_cast<unsigned char*>(out)[pix * Cout + o] = (unsigned char)rintf(u * 255.f);
+                }
+            }
+        }
+    }
+}
+
+extern "C" int lcm_conv3x3_smalln(const void* in, const void* W, const void* bias, void* out, void* out_f32, int B,
+                                  int H, int Wd, int Cin, int Cout, int mode, void* stream) {
+    LCM_REQUIRE(in && W && out, "conv_smalln: null pointer");
+    LCM_REQUIRE(B > 0 && H > 0 && Wd > 0 && Cin % 8 == 0 && Cout >= 1 && Cout <= 4, "conv_smalln: bad shape");
+    LCM_REQUIRE(mode == 0 || mode == 1, "conv_smalln: bad mode");
+    const int smem = Cout * 9 * Cin * 2;
+    LCM_REQUIRE(smem <= 64 * 1024, "conv_smalln: weights %d bytes exceed LDS budget", smem);
+    const long long npix = (long long)B * H * Wd;
+    hipStream_t s = (hipStream_t)stream;
+    const int ncc = Cin / 8;
+#define LAUNCH_SN(L)                                                                                              \
+    do {                                                                                                          \
+        const long long wg = (npix + (256 / L) - 1) / (256 / L);                                                  \
+        hipLaunchKernelGGL((conv_smalln_kernel<L>), dim3((int)(wg < 8192 ? wg : 8192)), dim3(256), smem, s,       \
+                           (const half_t*)in, (const half_t*)W, (const half_t*)bias, out, (float*)out_f32, B, H,  \
+                           Wd, Cin, Cout, mode);                                                                  \
+    } while (0)
+    if (ncc <= 16) LAUNCH_SN(16); else if (ncc <= 32) LAUNCH_SN(32); else LAUNCH_SN(64);
+#undef LAUNCH_SN
+    LCM_CHECK_LAUNCH("conv_smalln");
+    return LCM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// small-M linear: one wave per output feature n, lanes stride K in 16-byte chunks.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void linear_smallm_kernel(const half_t* __restrict__ x, int ldx,
+                                                            const half_t* __restrict__ W, const half_t* __restrict__ bias,
+                                                            const half_t* __restrict__ res, int ldr,
+                                                            half_t* __restrict__ out, int ldo, int M, int N, int K,
+                                                            int silu_in, int silu_out) {
+    const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    float acc[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) acc[m] = 0.f;
+    const half_t* wr = W + (long long)n * K;
+    for (int k = lane * 8; k < K; k += 512) {
+        h8 w = *reinterpret_cast<const h8*>(wr + k);
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            if (m < M) {
+                h8 xv = *reinterpret_cast<const h8*>(x + (long long)m * ldx + k);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float f = (float)xv[j];
+                    if (silu_in) f = silu_f(f);
+                    acc[m] += f * (float)w[j];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+        if (m < M) {
+            float v = wave_sum(acc[m]);
+            if (lane == 0) {
+                if (bias) v += (float)bias[n];
+                if (res) v += (float)res[(long long)m * ldr + n];
+                if (silu_out) v = silu_f(v);
+                out[(long long)m * ldo + n] = (half_t)v;
+            }
+        }
+    }
+}
+
+extern "C" int lcm_linear_smallm_f16(const void* x, int ldx, const void* W, const void* bias, const void* res, int ldr,
+                                     void* out, int ldo, int M, int N, int K, int silu_in, int silu_out, void* stream) {
+    LCM_REQUIRE(x && W && out, "linear_smallm: null pointer");
+    LCM_REQUIRE(M >= 1 && M <= 16 && N > 0 && K > 0 && K % 8 == 0 && ldx % 8 == 0, "linear_smallm: bad shape M=%d N=%d K=%d", M, N, K);
+    hipLaunchKernelGGL(linear_smallm_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const half_t*)x, ldx,
+                       (const half_t*)W, (const half_t*)bias, (const half_t*)res, ldr, (half_t*)out, ldo, M, N, K,
+                       silu_in, silu_out);
+    LCM_CHECK_LAUNCH("linear_smallm");
+    return LCM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void timestep_embedding_kernel(float t, half_t* __restrict__ out, int B, int dim) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int half = dim >> 1;
+    if (i >= B * dim) return;
+    const int j = i % dim;
+    const int k = j < half ? j : j - half;
+    const float f = expf(-9.210340371976184f * (float)k / (float)half);   // ln(10000)
+    const float a = t * f;
+    out[i] = (half_t)(j < half ? cosf(a) : sinf(a));
+}
+
+extern "C" int lcm_timestep_embedding(float t, void* out, int B, int dim, void* stream) {
+    LCM_REQUIRE(out && B > 0 && dim > 0 && dim % 2 == 0, "timestep_embedding: bad shape");
+    hipLaunchKernelGGL(timestep_embedding_kernel, dim3((B * dim + 255) / 256), dim3(256), 0, (hipStream_t)stream, t,
+                       (half_t*)out, B, dim);
+    LCM_CHECK_LAUNCH("timestep_embedding");
+    return LCM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+struct StepCoef { float sa, sb, c_skip, c_out, sap, sbp; };
+
+__global__ void scheduler_step_kernel(const float* __restrict__ eps, const float* __restrict__ eps_u, float guidance,
+                                      float* __restrict__ lat, const float* __restrict__ noise, StepCoef c, int last,
+                                      int B, int h, int w) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // NCHW index
+    const int hw = h * w, n = B * 4 * hw;
+    if (i >= n) return;
+    const int pix = i % hw, ch = (i / hw) & 3, b = i / (4 * hw);
+    const long long e = ((long long)b * hw + pix) * 4 + ch;   // NHWC
+    float ev = eps[e];
+    if (eps_u) { const float u = eps_u[e]; ev = u + guidance * (ev - u); }
+    const float x = lat[i];
+    const float x0 = (x - c.sb * ev) / c.sa;
+    const float den = c.c_out * x0 + c.c_skip * x;
+    lat[i] = last ? den : c.sap * den + c.sbp * noise[i];
+}
+
+extern "C" int lcm_scheduler_step(const void* eps, const void* eps_uncond, float guidance, void* lat, const void* noise,
+                                  const float* coef6, int last, int B, int h, int w, void* stream) {
+    LCM_REQUIRE(eps && lat && coef6 && (last || noise), "scheduler_step: null pointer");
+    LCM_REQUIRE(B > 0 && h > 0 && w > 0, "scheduler_step: bad shape");
+    StepCoef c = {coef6[0], coef6[1], coef6[2], coef6[3], coef6[4], coef6[5]};
+    const int n = B * 4 * h * w;
+    hipLaunchKernelGGL(scheduler_step_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)eps, (const float*)eps_uncond, guidance, (float*)lat, (const float*)noise, c, last,
+                       B, h, w);
+    LCM_CHECK_LAUNCH("scheduler_step");
+    return LCM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void latents_pool8_kernel(const float* __restrict__ lat, half_t* __restrict__ out, int B, int h, int w) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // (b, c, oy, ox)
+    if (i >= B * 4 * 64) return;
+    const int ox = i & 7, oy = (i >> 3) & 7, bc = i >> 6;
+    // adaptive_avg_pool2d bins: [floor(o*n/8), ceil((o+1)*n/8))
+    const int y0 = (oy * h) / 8, y1 = ((oy + 1) * h + 7) / 8;
+    const int x0 = (ox * w) / 8, x1 = ((ox + 1) * w + 7) / 8;
+    float s = 0.f;
+    for (int y = y0; y < y1; ++y)
+        for (int x = x0; x < x1; ++x) s += lat[((long long)bc * h + y) * w + x];
+    out[i] = (half_t)(s / (float)((y1 - y0) * (x1 - x0)));
+}
+
+extern "C" int lcm_latents_pool8(const void* lat, void* out_f16, int B, int h, int w, void* stream) {
+    LCM_REQUIRE(lat && out_f16 && B > 0 && h > 0 && w > 0, "latents_pool8: bad args");
+    hipLaunchKernelGGL(latents_pool8_kernel, dim3((B * 256 + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)lat, (half_t*)out_f16, B, h, w);
+    LCM_CHECK_LAUNCH("latents_pool8");
+    return LCM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// [R][C] -> [C][R] tiled transpose through LDS (64x64 tiles, padded rows).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_kernel(const half_t* __restrict__ in, int ldi, half_t* __restrict__ out,
+                                                        int ldo, int R, int C, long long stride_in, long long stride_out) {
+    __shared__ half_t tile[64][66];
+    const half_t* ib = in + blockIdx.z * stride_in;
+    half_t* ob = out + blockIdx.z * stride_out;
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < R && c < C) ? ib[(long long)r * ldi + c] : (half_t)0;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < C && r < R) ob[(long long)c * ldo + r] = tile[tx][i];
+    }
+}
+
+extern "C" int lcm_transpose_f16(const void* in, int ldi, void* out, int ldo, int R, int C, int batch, int64_t stride_in,
+                                 int64_t stride_out, void* stream) {
+    LCM_REQUIRE(in && out && R > 0 && C > 0 && batch > 0, "transpose: bad args");
+    hipLaunchKernelGGL(transpose_kernel, dim3((C + 63) / 64, (R + 63) / 64, batch), dim3(256), 0, (hipStream_t)stream,
+                       (const half_t*)in, ldi, (half_t*)out, ldo, R, C, (long long)stride_in, (long long)stride_out);
+    LCM_CHECK_LAUNCH("transpose");
+    return LCM_OK;
+}

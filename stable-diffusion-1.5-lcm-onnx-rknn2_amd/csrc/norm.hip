@@ -1,0 +1,254 @@
+// GroupNorm(+SiLU), LayerNorm and row softmax for pixel-major fp16 activations on gfx950.
+//
+// Replaces torch.nn.GroupNorm (+ F.silu) in ResnetBlock2D / Transformer2DModel / conv_norm_out,
+// torch.nn.LayerNorm in BasicTransformerBlock, and the softmax of the AutoencoderKL mid attention,
+// as reached from backends/cuda_worker.py:221-229.  All HBM-bound: 16-byte vector accesses, fp32
+// statistics, wave64 shuffle reductions, and NO atomics (bit-reproducible run to run: the worker
+// contract "same seed => identical PNG", tests/test_sdxl_worker.py:171-198).
+//
+// GroupNorm over [B][HW][C] (C = C1 (+C2 for the fused skip concat)) runs as
+//   1. gn_stats:    grid (chunks, B): per-channel partial sum / sum-of-squares of a row chunk, folded to
+//                   the 32 groups -> part[b][chunk][g][2]
+//   2. gn_finalize: one wave per (b, g): fixed-order reduction of the chunk partials -> mean, rstd
+//   3. gn_apply:    y = silu((x - mean) * rstd * gamma + beta), written as ONE concatenated tensor.
+#include "common.h"
+
+#define GN_ROWS 64          // rows of HW per stats workgroup
+#define GN_MAXC 2560
+#define GN_LDS_FLOATS 5120  // max(nrl * C, C) * 2
+
+__device__ __forceinline__ h8 load_cat8(const half_t* x, int C1, const half_t* x2, int C2, long long row, int c) {
+    // 8 channels starting at c of row `row` of the virtual concat [x | x2]; C1 % 8 == 0
+    return (c < C1) ? *reinterpret_cast<const h8*>(x + row * C1 + c)
+                    : *reinterpret_cast<const h8*>(x2 + row * C2 + (c - C1));
+}
+
+__global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* __restrict__ x, int C1,
+                                                       const half_t* __restrict__ x2, int C2,
+                                                       float* __restrict__ part, int HW, int groups, int nchunk) {
+    __shared__ float red[GN_LDS_FLOATS];
+    const int C = C1 + C2, ncc = C >> 3, cpg = C / groups;
+    const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    const int r0 = chunk * GN_ROWS, r1 = min(HW, r0 + GN_ROWS);
+    const long long rowbase = (long long)b * HW;
+    const int nrl = ncc <= 256 ? 256 / ncc : 1;        // row lanes
+    if (ncc <= 256) {
+        const int rl = tid / ncc, cc = tid - rl * ncc;
+        if (rl < nrl) {
+            float s[8], q[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
+            for (int r = r0 + rl; r < r1; r += nrl) {
+                h8 v = load_cat8(x, C1, x2, C2, rowbase + r, cc * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { float f = (float)v[j]; s[j] += f; q[j] += f * f; }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                red[(rl * C + cc * 8 + j) * 2 + 0] = s[j];
+                red[(rl * C + cc * 8 + j) * 2 + 1] = q[j];
+            }
+        }
+    } else {
+        for (int cc = tid; cc < ncc; cc += 256) {
+            float s[8], q[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
+            for (int r = r0; r < r1; ++r) {
+                h8 v = load_cat8(x, C1, x2, C2, rowbase + r, cc * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { float f = (float)v[j]; s[j] += f; q[j] += f * f; }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { red[(cc * 8 + j) * 2] = s[j]; red[(cc * 8 + j) * 2 + 1] = q[j]; }
+        }
+    }
+    __syncthreads();
+    if (tid < groups) {
+        float s = 0.f, q = 0.f;
+        for (int rl = 0; rl < nrl; ++rl)
+            for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) {
+                s += red[(rl * C + c) * 2];
+                q += red[(rl * C + c) * 2 + 1];
+            }
+        float* o = part + (((long long)b * nchunk + chunk) * groups + tid) * 2;
+        o[0] = s; o[1] = q;
+    }
+}
+
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ part, float* __restrict__ stats,
+                                                         int nchunk, int groups, float inv_count, float eps) {
+    const int bg = blockIdx.x;              // b*groups + g
+    const int b = bg / groups, g = bg - b * groups, lane = threadIdx.x;
+    float s = 0.f, q = 0.f;
+    for (int c = lane; c < nchunk; c += 64) {
+        const float* p = part + (((long long)b * nchunk + c) * groups + g) * 2;
+        s += p[0]; q += p[1];
+    }
+    s = wave_sum(s); q = wave_sum(q);
+    if (lane == 0) {
+        const float mean = s * inv_count;
+        const float var = fmaxf(q * inv_count - mean * mean, 0.f);
+        stats[bg * 2] = mean;
+        stats[bg * 2 + 1] = rsqrtf(var + eps);
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict__ x, int C1,
+                                                       const half_t* __restrict__ x2, int C2,
+                                                       const half_t* __restrict__ gamma, const half_t* __restrict__ beta,
+                                                       const float* __restrict__ stats, half_t* __restrict__ out,
+                                                       int HW, int groups, int silu, int rows_per_wg) {
+    __shared__ float st[128];
+    const int C = C1 + C2, ncc = C >> 3, cpg = C / groups;
+    const int b = blockIdx.y, tid = threadIdx.x;
+    if (tid < groups * 2) st[tid] = stats[b * groups * 2 + tid];
+    __syncthreads();
+    const int r0 = blockIdx.x * rows_per_wg, r1 = min(HW, r0 + rows_per_wg);
+    const long long rowbase = (long long)b * HW;
+    const int total = (r1 - r0) * ncc;
+    for (int i = tid; i < total; i += 256) {
+        const int r = r0 + i / ncc, cc = i % ncc, c = cc * 8;
+        h8 v = load_cat8(x, C1, x2, C2, rowbase + r, c);
+        h8 gm = *reinterpret_cast<const h8*>(gamma + c);
+        h8 bt = *reinterpret_cast<const h8*>(beta + c);
+        h8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int g = (c + j) / cpg;
+            float f = ((float)v[j] - st[g * 2]) * st[g * 2 + 1] * (float)gm[j] + (float)bt[j];
+            if (silu) f = silu_f(f);
+            o[j] = (half_t)f;
+        }
+        *reinterpret_cast<h8*>(out + (rowbase + r) * C + c) = o;
+    }
+}
+
+static inline int gn_nchunk(int HW) { return (HW + GN_ROWS - 1) / GN_ROWS; }
+
+extern "C" int64_t lcm_groupnorm_ws_bytes(int B, int HW, int C, int groups) {
+    (void)C;
+    return ((int64_t)B * gn_nchunk(HW) * groups * 2 + (int64_t)B * groups * 2) * 4;
+}
+
+extern "C" int lcm_groupnorm_f16(const void* x, int C1, const void* x2, int C2, const void* gamma,
+                                 const void* beta, void* out, int B, int HW, int groups, float eps, int silu,
+                                 void* ws, void* stream) {
+    LCM_REQUIRE(x && gamma && beta && out && ws, "groupnorm: null pointer");
+    if (!x2) C2 = 0;
+    const int C = C1 + C2;
+    LCM_REQUIRE(B > 0 && HW > 0 && groups > 0 && groups <= 64, "groupnorm: bad shape B=%d HW=%d G=%d", B, HW, groups);
+    LCM_REQUIRE(C1 % 8 == 0 && C2 % 8 == 0 && C % groups == 0 && C <= GN_MAXC, "groupnorm: bad channels %d+%d", C1, C2);
+    hipStream_t s = (hipStream_t)stream;
+    const int nchunk = gn_nchunk(HW);
+    float* part = (float*)ws;
+    float* stats = part + (long long)B * nchunk * groups * 2;
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, B), dim3(256), 0, s, (const half_t*)x, C1, (const half_t*)x2, C2,
+                       part, HW, groups, nchunk);
+    LCM_CHECK_LAUNCH("gn_stats");
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * groups), dim3(64), 0, s, part, stats, nchunk, groups,
+                       1.0f / ((float)HW * (float)(C / groups)), eps);
+    LCM_CHECK_LAUNCH("gn_finalize");
+    const int rows_per_wg = max(1, 2048 / (C >> 3));   // ~8 vectors per thread
+    hipLaunchKernelGGL(gn_apply_kernel, dim3((HW + rows_per_wg - 1) / rows_per_wg, B), dim3(256), 0, s,
+                       (const half_t*)x, C1, (const half_t*)x2, C2, (const half_t*)gamma, (const half_t*)beta, stats,
+                       (half_t*)out, HW, groups, silu, rows_per_wg);
+    LCM_CHECK_LAUNCH("gn_apply");
+    return LCM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm: one wave per row, row held in registers (C <= 1536), two-pass statistics.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict__ x, const half_t* __restrict__ gamma,
+                                                        const half_t* __restrict__ beta, half_t* __restrict__ out,
+                                                        int M, int C, float eps) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int ncc = C >> 3;
+    const half_t* xr = x + (long long)row * C;
+    h8 v[3];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int cc = lane + 64 * i;
+        if (cc < ncc) {
+            v[i] = *reinterpret_cast<const h8*>(xr + cc * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += (float)v[i][j];
+        }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int cc = lane + 64 * i;
+        if (cc < ncc) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { float d = (float)v[i][j] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+    half_t* orow = out + (long long)row * C;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int cc = lane + 64 * i;
+        if (cc < ncc) {
+            h8 gm = *reinterpret_cast<const h8*>(gamma + cc * 8);
+            h8 bt = *reinterpret_cast<const h8*>(beta + cc * 8);
+            h8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (half_t)(((float)v[i][j] - mean) * rstd * (float)gm[j] + (float)bt[j]);
+            *reinterpret_cast<h8*>(orow + cc * 8) = o;
+        }
+    }
+}
+
+extern "C" int lcm_layernorm_f16(const void* x, const void* gamma, const void* beta, void* out, int M, int C,
+                                 float eps, void* stream) {
+    LCM_REQUIRE(x && gamma && beta && out, "layernorm: null pointer");
+    LCM_REQUIRE(M > 0 && C > 0 && C % 8 == 0 && C <= 1536, "layernorm: bad shape M=%d C=%d", M, C);
+    hipLaunchKernelGGL(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const half_t*)x,
+                       (const half_t*)gamma, (const half_t*)beta, (half_t*)out, M, C, eps);
+    LCM_CHECK_LAUNCH("layernorm");
+    return LCM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row softmax in place: one wave per row, n % 8 == 0, n <= 64*8*16 = 8192 per pass (looped).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void softmax_rows_kernel(half_t* __restrict__ x, int rows, int n, int ld) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    half_t* xr = x + (long long)row * ld;
+    const int ncc = n >> 3;
+    float m = -3.0e38f;
+    for (int cc = lane; cc < ncc; cc += 64) {
+        h8 v = *reinterpret_cast<const h8*>(xr + cc * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m = fmaxf(m, (float)v[j]);
+    }
+    m = wave_max(m);
+    float s = 0.f;
+    for (int cc = lane; cc < ncc; cc += 64) {
+        h8 v = *reinterpret_cast<const h8*>(xr + cc * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += __expf((float)v[j] - m);
+    }
+    const float inv = 1.0f / wave_sum(s);
+    for (int cc = lane; cc < ncc; cc += 64) {
+        h8 v = *reinterpret_cast<const h8*>(xr + cc * 8);
+        h8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (half_t)(__expf((float)v[j] - m) * inv);
+        *reinterpret_cast<h8*>(xr + cc * 8) = o;
+    }
+}
+
+extern "C" int lcm_softmax_rows_f16(void* x, int rows, int n, int ld, void* stream) {
+    LCM_REQUIRE(x && rows > 0 && n > 0 && n % 8 == 0 && ld % 8 == 0, "softmax: bad shape rows=%d n=%d ld=%d", rows, n, ld);
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (half_t*)x, rows,
+                       n, ld);
+    LCM_CHECK_LAUNCH("softmax_rows");
+    return LCM_OK;
+}

@@ -1,0 +1,83 @@
+"""ctypes binding of liblcmhip.so (the C ABI declared in include/lcm_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing or a call fails, a
+``LcmHipError`` is raised (the worker pool turns it into a failed future / HTTP 500,
+backends/worker_pool.py:333-336 in the reference).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblcmhip.so")
+
+
+class LcmHipError(RuntimeError):
+    pass
+
+
+def build(verbose: bool = False) -> str:
+    """Compile csrc/*.hip for gfx950 into liblcmhip.so (hipcc cross-compiles without a GPU)."""
+    r = subprocess.run(["make", "-C", os.path.join(_HERE, "csrc"), "-j8"], capture_output=True, text=True)
+    if verbose or r.returncode != 0:
+        print(r.stdout[-4000:], r.stderr[-4000:])
+    if r.returncode != 0:
+        raise LcmHipError("building liblcmhip.so failed")
+    return LIB_PATH
+
+
+_vp, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
+
+_SIGS = {
+    "lcm_gemm_f16": [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _i,
+                     _i64, _i64, _i64, _vp],
+    "lcm_conv3x3_f16": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "lcm_conv3x3_c4_f32in": [_vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "lcm_conv3x3_smalln": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "lcm_groupnorm_f16": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp],
+    "lcm_layernorm_f16": [_vp, _vp, _vp, _vp, _i, _i, _f, _vp],
+    "lcm_attention_f16": [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp],
+    "lcm_softmax_rows_f16": [_vp, _i, _i, _i, _vp],
+    "lcm_transpose_f16": [_vp, _i, _vp, _i, _i, _i, _i, _i64, _i64, _vp],
+    "lcm_linear_smallm_f16": [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "lcm_timestep_embedding": [_f, _vp, _i, _i, _vp],
+    "lcm_scheduler_step": [_vp, _vp, _f, _vp, _vp, C.POINTER(C.c_float), _i, _i, _i, _i, _vp],
+    "lcm_latents_pool8": [_vp, _vp, _i, _i, _i, _vp],
+    "lcm_graph_begin": [_vp],
+    "lcm_graph_end": [_vp, C.POINTER(_vp)],
+    "lcm_graph_launch": [_vp, _vp],
+    "lcm_graph_destroy": [_vp],
+    "lcm_device_info": [_i, C.c_char_p, _i, C.POINTER(_i), C.POINTER(C.c_uint64)],
+}
+EXPORTS = tuple(sorted(list(_SIGS) + ["lcm_last_error", "lcm_version", "lcm_groupnorm_ws_bytes"]))
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LcmHipError(f"{LIB_PATH} not built: run __graft_entry__.build() (make -C csrc); "
+                          "there is no CPU fallback for the HIP path")
+    lib = C.CDLL(LIB_PATH)
+    for name, sig in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = sig
+        fn.restype = _i
+    lib.lcm_last_error.restype = C.c_char_p
+    lib.lcm_last_error.argtypes = []
+    lib.lcm_version.restype = _i
+    lib.lcm_groupnorm_ws_bytes.restype = _i64
+    lib.lcm_groupnorm_ws_bytes.argtypes = [_i, _i, _i, _i]
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().lcm_last_error().decode("utf-8", "replace")
+        raise LcmHipError(f"{what or 'lcm call'} failed (rc={rc}): {msg}")

@@ -1,0 +1,158 @@
+"""Thin torch-tensor front end of the C ABI: pointers + sizes in, kernels enqueued on the current
+torch HIP stream.  torch is plumbing here (device memory, streams); all arithmetic is in liblcmhip.so.
+Activations are pixel-major fp16 ``[B*H*W, C]`` tensors."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import lib as _lib
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def gemm(a, w, out, *, bias=None, res=None, rowadd=None, rows_per_batch=0, a2=None, epilogue=0, out_scale=1.0,
+         M=None, N=None, K=None, lda=None, ldo=None, batch=1, strideA=0, strideW=0, strideO=0):
+    """out[m][n] = out_scale * sum_k [a|a2][m][k] w[n][k] + bias + rowadd + res  (see include/lcm_hip.h)."""
+    L = _lib.load()
+    M = a.shape[0] if M is None else M
+    K1 = a.shape[-1] if a2 is not None else 0
+    K = (a.shape[-1] + (a2.shape[-1] if a2 is not None else 0)) if K is None else K
+    N = w.shape[0] if N is None else N
+    lda = a.stride(-2) if lda is None else lda
+    ldo = out.stride(-2) if ldo is None else ldo
+    rc = L.lcm_gemm_f16(_p(a), lda, _p(a2), a2.stride(0) if a2 is not None else 0, K1, _p(w), _p(bias), _p(rowadd),
+                        rowadd.stride(0) if rowadd is not None else 0, rows_per_batch,
+                        _p(res), res.stride(0) if res is not None else 0, _p(out), ldo,
+                        M, N, K, epilogue, float(out_scale), batch, strideA, strideW, strideO, _stream())
+    _lib.check(rc, "lcm_gemm_f16")
+    return out
+
+
+def conv3x3(x, w, out, B, H, W, Cin, Cout, *, bias=None, rowadd=None, res=None, stride=1, ups=0):
+    L = _lib.load()
+    rc = L.lcm_conv3x3_f16(_p(x), _p(w), _p(bias), _p(rowadd), rowadd.stride(0) if rowadd is not None else 0,
+                           _p(res), _p(out), B, H, W, Cin, Cout, stride, ups, _stream())
+    _lib.check(rc, "lcm_conv3x3_f16")
+    return out
+
+
+def conv3x3_c4(lat_f32, w, out, B, H, W, Cout, *, bias=None, pre_w=None, pre_b=None, in_scale=1.0):
+    L = _lib.load()
+    rc = L.lcm_conv3x3_c4_f32in(_p(lat_f32), _p(pre_w), _p(pre_b), float(in_scale), _p(w), _p(bias), _p(out),
+                                B, H, W, Cout, _stream())
+    _lib.check(rc, "lcm_conv3x3_c4_f32in")
+    return out
+
+
+def conv3x3_smalln(x, w, out, B, H, W, Cin, Cout, *, bias=None, mode=0, out_f32=None):
+    L = _lib.load()
+    rc = L.lcm_conv3x3_smalln(_p(x), _p(w), _p(bias), _p(out), _p(out_f32), B, H, W, Cin, Cout, mode, _stream())
+    _lib.check(rc, "lcm_conv3x3_smalln")
+    return out
+
+
+def groupnorm_ws_bytes(B, HW, C, groups=32):
+    return int(_lib.load().lcm_groupnorm_ws_bytes(B, HW, C, groups))
+
+
+def groupnorm(x, gamma, beta, out, B, HW, C1, ws, *, x2=None, C2=0, groups=32, eps=1e-5, silu=True):
+    L = _lib.load()
+    rc = L.lcm_groupnorm_f16(_p(x), C1, _p(x2), C2, _p(gamma), _p(beta), _p(out), B, HW, groups, float(eps),
+                             1 if silu else 0, _p(ws), _stream())
+    _lib.check(rc, "lcm_groupnorm_f16")
+    return out
+
+
+def layernorm(x, gamma, beta, out, M, C, eps=1e-5):
+    L = _lib.load()
+    _lib.check(L.lcm_layernorm_f16(_p(x), _p(gamma), _p(beta), _p(out), M, C, float(eps), _stream()), "lcm_layernorm_f16")
+    return out
+
+
+def attention(q, k, v, out, B, heads, Sq, Sk, d, *, ldq, ldk, ldv, ldo, scale=None):
+    L = _lib.load()
+    scale = d ** -0.5 if scale is None else scale
+    rc = L.lcm_attention_f16(_p(q), ldq, _p(k), ldk, _p(v), ldv, _p(out), ldo, B, heads, Sq, Sk, d, float(scale), _stream())
+    _lib.check(rc, "lcm_attention_f16")
+    return out
+
+
+def softmax_rows(x, rows, n, ld):
+    L = _lib.load()
+    _lib.check(L.lcm_softmax_rows_f16(_p(x), rows, n, ld, _stream()), "lcm_softmax_rows_f16")
+    return x
+
+
+def transpose(x, out, R, Cc, *, ldi, ldo, batch=1, stride_in=0, stride_out=0):
+    L = _lib.load()
+    _lib.check(L.lcm_transpose_f16(_p(x), ldi, _p(out), ldo, R, Cc, batch, stride_in, stride_out, _stream()), "lcm_transpose_f16")
+    return out
+
+
+def linear_smallm(x, w, out, M, N, K, *, bias=None, res=None, silu_in=False, silu_out=False, ldx=None, ldo=None):
+    L = _lib.load()
+    rc = L.lcm_linear_smallm_f16(_p(x), x.stride(0) if ldx is None else ldx, _p(w), _p(bias), _p(res),
+                                 res.stride(0) if res is not None else 0, _p(out), out.stride(0) if ldo is None else ldo,
+                                 M, N, K, int(silu_in), int(silu_out), _stream())
+    _lib.check(rc, "lcm_linear_smallm_f16")
+    return out
+
+
+def timestep_embedding(t, out, B, dim):
+    L = _lib.load()
+    _lib.check(L.lcm_timestep_embedding(float(t), _p(out), B, dim, _stream()), "lcm_timestep_embedding")
+    return out
+
+
+def scheduler_step(eps, lat, noise, coef6, last, B, h, w, *, eps_uncond=None, guidance=1.0):
+    L = _lib.load()
+    arr = (C.c_float * 6)(*[float(c) for c in coef6])
+    rc = L.lcm_scheduler_step(_p(eps), _p(eps_uncond), float(guidance), _p(lat), _p(noise), arr, int(bool(last)),
+                              B, h, w, _stream())
+    _lib.check(rc, "lcm_scheduler_step")
+    return lat
+
+
+def latents_pool8(lat, out, B, h, w):
+    L = _lib.load()
+    _lib.check(L.lcm_latents_pool8(_p(lat), _p(out), B, h, w, _stream()), "lcm_latents_pool8")
+    return out
+
+
+class Graph:
+    """hipGraph captured from the kernels enqueued on the current torch stream."""
+
+    def __init__(self):
+        self._exec = C.c_void_p()
+
+    def __enter__(self):
+        _lib.check(_lib.load().lcm_graph_begin(_stream()), "lcm_graph_begin")
+        return self
+
+    def __exit__(self, et, ev, tb):
+        rc = _lib.load().lcm_graph_end(_stream(), C.byref(self._exec))
+        if et is None:
+            _lib.check(rc, "lcm_graph_end")
+        return False
+
+    def launch(self):
+        _lib.check(_lib.load().lcm_graph_launch(self._exec, _stream()), "lcm_graph_launch")
+
+    def close(self):
+        if self._exec:
+            _lib.load().lcm_graph_destroy(self._exec)
+            self._exec = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

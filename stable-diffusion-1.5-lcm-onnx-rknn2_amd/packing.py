@@ -1,0 +1,33 @@
+"""Host-side weight packing: diffusers parameter layouts -> the kernel layouts of liblcmhip.so.
+
+* 3x3 conv OIHW            -> [Cout][ky][kx][Cin]   (implicit-GEMM k order: tap major, channel minor)
+* 1x1 conv / linear         -> [N][K] as is
+* GEGLU proj (value|gate)   -> rows interleaved in blocks of 16 so value/gate of one output column land in
+                               the same lane of adjacent MFMA tiles (csrc/igemm.hip epilogue)
+* to_q|to_k|to_v            -> one [3C][C] matrix; cross-attention to_k|to_v -> [2C][768]
+"""
+from __future__ import annotations
+
+import torch
+
+
+def pack_conv3x3(w: torch.Tensor) -> torch.Tensor:
+    return w.permute(0, 2, 3, 1).contiguous().reshape(w.shape[0], -1)
+
+
+def pack_conv1x1(w: torch.Tensor) -> torch.Tensor:
+    return w.reshape(w.shape[0], -1).contiguous()
+
+
+def pack_geglu(w: torch.Tensor, b: torch.Tensor | None):
+    """w: [2F][K] with rows [0,F) = value, [F,2F) = gate (diffusers GEGLU: proj(x).chunk(2))."""
+    F2, K = w.shape
+    Fh = F2 // 2
+    assert Fh % 16 == 0
+    val = w[:Fh].reshape(Fh // 16, 16, K)
+    gate = w[Fh:].reshape(Fh // 16, 16, K)
+    wp = torch.stack([val, gate], dim=1).reshape(F2, K).contiguous()
+    bp = None
+    if b is not None:
+        bp = torch.stack([b[:Fh].reshape(-1, 16), b[Fh:].reshape(-1, 16)], dim=1).reshape(F2).contiguous()
+    return wp, bp

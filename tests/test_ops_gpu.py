@@ -1,0 +1,281 @@
+"""Per-kernel parity: every C-ABI entry point against the plain torch fp32 op it replaces.
+
+Inputs are fp16-rounded, references are computed on the CPU in fp32 from the same rounded values
+(the ops diffusers dispatches: F.linear / F.conv2d / F.group_norm / F.layer_norm / SDPA).
+Tolerance: fp16 output rounding (2^-11 relative) plus accumulation-order noise.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from sdlcm_amd import ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(torch.float16)
+
+
+def to_nhwc(x):  # [B,C,H,W] -> [B*H*W, C]
+    B, C, H, W = x.shape
+    return x.permute(0, 2, 3, 1).reshape(B * H * W, C).contiguous()
+
+
+def from_nhwc(y, B, H, W):
+    return y.reshape(B, H, W, -1).permute(0, 3, 1, 2)
+
+
+def close(got, ref, rtol=4e-3, atol=None, what=""):
+    got = got.float().cpu()
+    ref = ref.float().cpu()
+    scale = ref.abs().max().item() + 1e-6
+    atol = 2e-3 * scale if atol is None else atol
+    err = (got - ref).abs()
+    bad = err > (atol + rtol * ref.abs())
+    assert not bad.any(), f"{what}: max err {err.max().item():.4g} (scale {scale:.3g}), {bad.sum().item()} bad of {bad.numel()}"
+
+
+def pack3x3(w):  # OIHW -> [O][ky][kx][I]
+    return w.permute(0, 2, 3, 1).contiguous().reshape(w.shape[0], -1)
+
+
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(4096, 320, 320), (1000, 640, 1280), (77, 1280, 768), (64, 1280, 2560),
+                                   (1, 64, 64), (333, 128, 128), (4096, 2560, 320)])
+def test_gemm_plain(M, N, K):
+    a, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+    out = torch.empty(M, N, dtype=torch.float16, device=DEV)
+    ops.gemm(a.to(DEV), w.to(DEV), out, bias=b.to(DEV))
+    close(out, F.linear(a.float(), w.float(), b.float()), what=f"gemm {M}x{N}x{K}")
+
+
+def test_gemm_epilogues_and_split():
+    M, N, K1, K2, rpb = 512, 320, 640, 320, 128
+    a1, a2 = rnd(M, K1, seed=1), rnd(M, K2, seed=2)
+    w = rnd(N, K1 + K2, seed=3, scale=(K1 + K2) ** -0.5)
+    b, res, radd = rnd(N, seed=4), rnd(M, N, seed=5), rnd(M // rpb, N, seed=6)
+    out = torch.empty(M, N, dtype=torch.float16, device=DEV)
+    ops.gemm(a1.to(DEV), w.to(DEV), out, a2=a2.to(DEV), bias=b.to(DEV), res=res.to(DEV), rowadd=radd.to(DEV),
+             rows_per_batch=rpb, out_scale=0.5)
+    ref = (F.linear(torch.cat([a1, a2], 1).float(), w.float(), b.float())
+           + radd.float().repeat_interleave(rpb, 0)) * 0.5 + res.float()
+    close(out, ref, what="gemm split/epilogue")
+
+
+def test_gemm_geglu():
+    M, C = 300, 320
+    a = rnd(M, C, seed=1)
+    w = rnd(8 * C, C, seed=2, scale=C ** -0.5)
+    b = rnd(8 * C, seed=3)
+    from sdlcm_amd.packing import pack_geglu
+    wp, bp = pack_geglu(w, b)
+    out = torch.empty(M, 4 * C, dtype=torch.float16, device=DEV)
+    ops.gemm(a.to(DEV), wp.to(DEV), out, bias=bp.to(DEV), epilogue=1)
+    h, g = F.linear(a.float(), w.float(), b.float()).chunk(2, dim=-1)
+    close(out, h * F.gelu(g), what="geglu")
+
+
+def test_gemm_batched_strided():
+    Z, M, N, K = 3, 256, 192, 512
+    a, w = rnd(Z, M, K, seed=1), rnd(Z, N, K, seed=2, scale=K ** -0.5)
+    out = torch.empty(Z, M, N, dtype=torch.float16, device=DEV)
+    ops.gemm(a.to(DEV), w.to(DEV), out, M=M, N=N, K=K, lda=K, ldo=N, batch=Z, strideA=M * K, strideW=N * K,
+             strideO=M * N, out_scale=0.25)
+    close(out, torch.einsum("zmk,znk->zmn", a.float(), w.float()) * 0.25, what="batched gemm")
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,stride,ups", [
+    (1, 64, 64, 320, 320, 1, 0), (2, 16, 16, 640, 1280, 1, 0), (1, 32, 32, 320, 320, 2, 0),
+    (1, 8, 8, 1280, 1280, 1, 1), (3, 1, 1, 128, 64, 1, 0), (1, 2, 2, 64, 128, 2, 0), (1, 5, 7, 128, 64, 1, 0),
+    (2, 24, 40, 128, 128, 1, 1)])
+def test_conv3x3(B, H, W, Cin, Cout, stride, ups):
+    x = rnd(B, Cin, H, W, seed=1)
+    w = rnd(Cout, Cin, 3, 3, seed=2, scale=(9 * Cin) ** -0.5)
+    b = rnd(Cout, seed=3)
+    xin = F.interpolate(x.float(), scale_factor=2.0, mode="nearest") if ups else x.float()
+    ref = F.conv2d(xin, w.float(), b.float(), stride=stride, padding=1)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    radd = rnd(B, Cout, seed=4)
+    res = rnd(B, Cout, Ho, Wo, seed=5)
+    ref = ref + radd.float()[:, :, None, None] + res.float()
+    out = torch.empty(B * Ho * Wo, Cout, dtype=torch.float16, device=DEV)
+    ops.conv3x3(to_nhwc(x).to(DEV), pack3x3(w).to(DEV), out, B, H, W, Cin, Cout, bias=b.to(DEV), rowadd=radd.to(DEV),
+                res=to_nhwc(res).to(DEV), stride=stride, ups=ups)
+    close(from_nhwc(out, B, Ho, Wo), ref, what="conv3x3")
+
+
+@pytest.mark.parametrize("pre", [False, True])
+def test_conv_c4(pre):
+    B, H, W, Cout = 2, 24, 16, 320
+    lat = torch.randn(B, 4, H, W, generator=torch.Generator().manual_seed(1))
+    w = rnd(Cout, 4, 3, 3, seed=2, scale=1 / 6)
+    b = rnd(Cout, seed=3)
+    pw = torch.randn(4, 4, generator=torch.Generator().manual_seed(4)) * 0.5
+    pb = torch.randn(4, generator=torch.Generator().manual_seed(5)) * 0.1
+    z = lat
+    if pre:
+        z = F.conv2d(lat / 0.18215, pw[:, :, None, None], pb)
+    ref = F.conv2d(z, w.float(), b.float(), padding=1)
+    out = torch.empty(B * H * W, Cout, dtype=torch.float16, device=DEV)
+    ops.conv3x3_c4(lat.to(DEV), pack3x3(w).to(DEV), out, B, H, W, Cout, bias=b.to(DEV),
+                   pre_w=pw.to(DEV) if pre else None, pre_b=pb.to(DEV) if pre else None,
+                   in_scale=1 / 0.18215 if pre else 1.0)
+    close(from_nhwc(out, B, H, W), ref, what="conv_c4")
+
+
+@pytest.mark.parametrize("Cin,Cout,mode", [(320, 4, 0), (128, 3, 1), (256, 3, 1)])
+def test_conv_smalln(Cin, Cout, mode):
+    B, H, W = 2, 20, 12
+    x = rnd(B, Cin, H, W, seed=1)
+    w = rnd(Cout, Cin, 3, 3, seed=2, scale=(9 * Cin) ** -0.5)
+    b = rnd(Cout, seed=3, scale=0.1)
+    ref = F.conv2d(x.float(), w.float(), b.float(), padding=1)
+    of = torch.empty(B * H * W, Cout, dtype=torch.float32, device=DEV)
+    if mode == 0:
+        ops.conv3x3_smalln(to_nhwc(x).to(DEV), pack3x3(w).to(DEV), of, B, H, W, Cin, Cout, bias=b.to(DEV), mode=0)
+        close(from_nhwc(of, B, H, W), ref, rtol=1e-4, atol=1e-4, what="conv_smalln f32")
+    else:
+        o8 = torch.empty(B * H * W, Cout, dtype=torch.uint8, device=DEV)
+        ops.conv3x3_smalln(to_nhwc(x).to(DEV), pack3x3(w).to(DEV), o8, B, H, W, Cin, Cout, bias=b.to(DEV), mode=1,
+                           out_f32=of)
+        close(from_nhwc(of, B, H, W), ref, rtol=1e-4, atol=1e-4, what="conv_smalln f32 copy")
+        # u8 must be the reference post-process of the kernel's own float output (ties/half-even included)
+        exp = (np.clip(of.cpu().numpy() / 2 + 0.5, 0, 1) * 255).round().astype(np.uint8)
+        got = o8.cpu().numpy()
+        assert np.abs(got.astype(int) - exp.astype(int)).max() <= 1
+        assert (got != exp).mean() < 1e-3
+
+
+@pytest.mark.parametrize("B,HW,C1,C2,silu,eps", [(2, 4096, 320, 0, True, 1e-5), (1, 256, 1280, 640, True, 1e-5),
+                                                (2, 64, 1280, 1280, True, 1e-5), (1, 1024, 640, 320, True, 1e-5),
+                                                (1, 1, 1280, 0, True, 1e-5), (1, 5000, 128, 0, True, 1e-6),
+                                                (3, 100, 512, 0, False, 1e-6)])
+def test_groupnorm(B, HW, C1, C2, silu, eps):
+    C = C1 + C2
+    x1 = rnd(B * HW, C1, seed=1) * 2 + 0.5
+    x2 = (rnd(B * HW, C2, seed=2) * 0.5 - 1.0) if C2 else None
+    gamma, beta = (1 + 0.1 * rnd(C, seed=3).float()).half(), rnd(C, seed=4, scale=0.1)
+    xc = torch.cat([x1, x2], 1) if C2 else x1
+    ref = F.group_norm(xc.float().reshape(B, HW, C).permute(0, 2, 1), 32, gamma.float(), beta.float(), eps)
+    if silu:
+        ref = F.silu(ref)
+    ref = ref.permute(0, 2, 1).reshape(B * HW, C)
+    ws = torch.empty(ops.groupnorm_ws_bytes(B, HW, C) // 4, dtype=torch.float32, device=DEV)
+    out = torch.empty(B * HW, C, dtype=torch.float16, device=DEV)
+    ops.groupnorm(x1.to(DEV), gamma.to(DEV), beta.to(DEV), out, B, HW, C1, ws, x2=x2.to(DEV) if C2 else None, C2=C2,
+                  eps=eps, silu=silu)
+    close(out, ref, what="groupnorm")
+
+
+@pytest.mark.parametrize("M,C", [(4096, 320), (77, 640), (5, 1280)])
+def test_layernorm(M, C):
+    x = rnd(M, C, seed=1) * 3 + 1
+    g, b = (1 + 0.1 * rnd(C, seed=2).float()).half(), rnd(C, seed=3, scale=0.1)
+    out = torch.empty(M, C, dtype=torch.float16, device=DEV)
+    ops.layernorm(x.to(DEV), g.to(DEV), b.to(DEV), out, M, C)
+    close(out, F.layer_norm(x.float(), (C,), g.float(), b.float(), 1e-5), what="layernorm")
+
+
+@pytest.mark.parametrize("B,heads,Sq,Sk,d", [(1, 8, 4096, 4096, 40), (2, 8, 1024, 1024, 80), (2, 8, 256, 256, 160),
+                                            (1, 8, 64, 64, 160), (2, 8, 4096, 77, 40), (1, 8, 1024, 77, 80),
+                                            (3, 8, 256, 77, 160), (1, 8, 16, 16, 160), (1, 8, 1, 1, 160),
+                                            (1, 8, 200, 130, 80), (1, 2, 100, 77, 64)])
+def test_attention(B, heads, Sq, Sk, d):
+    C = heads * d
+    q, k, v = rnd(B * Sq, C, seed=1), rnd(B * Sk, C, seed=2), rnd(B * Sk, C, seed=3)
+    qh = q.float().reshape(B, Sq, heads, d).transpose(1, 2)
+    kh = k.float().reshape(B, Sk, heads, d).transpose(1, 2)
+    vh = v.float().reshape(B, Sk, heads, d).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(B * Sq, C)
+    out = torch.empty(B * Sq, C, dtype=torch.float16, device=DEV)
+    ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), out, B, heads, Sq, Sk, d, ldq=C, ldk=C, ldv=C, ldo=C)
+    close(out, ref, rtol=6e-3, what=f"attention B{B} S{Sq}x{Sk} d{d}")
+
+
+def test_attention_peaked_softmax():
+    """Forces the online-softmax rescale path: one key dominates late in the sequence."""
+    B, heads, S, d = 1, 8, 512, 40
+    C = heads * d
+    q, k, v = rnd(S, C, seed=1), rnd(S, C, seed=2), rnd(S, C, seed=3)
+    k[300] = q[7] * 6   # spike
+    k[470] = q[100] * 8
+    qh, kh, vh = (t.float().reshape(B, S, heads, d).transpose(1, 2) for t in (q, k, v))
+    ref = F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(S, C)
+    out = torch.empty(S, C, dtype=torch.float16, device=DEV)
+    ops.attention(q.to(DEV), k.to(DEV), v.to(DEV), out, B, heads, S, S, d, ldq=C, ldk=C, ldv=C, ldo=C)
+    close(out, ref, rtol=6e-3, what="attention peaked")
+
+
+def test_attention_strided_qkv():
+    """Fused QKV buffer: q/k/v are column slices of one [B*S, 3C] tensor."""
+    B, heads, S, d = 2, 8, 256, 40
+    C = heads * d
+    qkv = rnd(B * S, 3 * C, seed=1)
+    qh, kh, vh = (qkv[:, i * C:(i + 1) * C].float().reshape(B, S, heads, d).transpose(1, 2) for i in range(3))
+    ref = F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(B * S, C)
+    t = qkv.to(DEV)
+    out = torch.empty(B * S, C, dtype=torch.float16, device=DEV)
+    ops.attention(t[:, :C], t[:, C:2 * C], t[:, 2 * C:], out, B, heads, S, S, d, ldq=3 * C, ldk=3 * C, ldv=3 * C, ldo=C)
+    close(out, ref, rtol=6e-3, what="attention strided")
+
+
+def test_softmax_and_transpose():
+    x = rnd(300, 4096, seed=1) * 3
+    t = x.to(DEV).clone()
+    ops.softmax_rows(t, 300, 4096, 4096)
+    close(t, torch.softmax(x.float(), -1), rtol=4e-3, atol=1e-5, what="softmax")
+    a = rnd(2, 100, 200, seed=2)
+    o = torch.empty(2, 200, 100, dtype=torch.float16, device=DEV)
+    ops.transpose(a.to(DEV), o, 100, 200, ldi=200, ldo=100, batch=2, stride_in=100 * 200, stride_out=200 * 100)
+    assert torch.equal(o.cpu(), a.transpose(1, 2))
+
+
+@pytest.mark.parametrize("M,N,K,si,so", [(1, 1280, 320, False, True), (8, 20160, 1280, True, False), (3, 320, 256, False, False)])
+def test_linear_smallm(M, N, K, si, so):
+    x, w, b, r = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3), rnd(M, N, seed=4)
+    out = torch.empty(M, N, dtype=torch.float16, device=DEV)
+    ops.linear_smallm(x.to(DEV), w.to(DEV), out, M, N, K, bias=b.to(DEV), res=r.to(DEV), silu_in=si, silu_out=so)
+    xin = F.silu(x.float()) if si else x.float()
+    ref = F.linear(xin, w.float(), b.float()) + r.float()
+    close(out, F.silu(ref) if so else ref, what="linear_smallm")
+
+
+def test_timestep_embedding_and_step_and_pool():
+    from oracle.unet import timestep_sinusoid
+    from oracle.scheduler import LCMSchedulerOracle
+    from oracle import glue
+    out = torch.empty(3, 320, dtype=torch.float16, device=DEV)
+    for t in (999, 259, 19):
+        ops.timestep_embedding(t, out, 3, 320)
+        close(out, timestep_sinusoid(torch.tensor([t] * 3), 320), rtol=1e-3, atol=1.5e-3, what=f"temb t={t}")
+    s = LCMSchedulerOracle()
+    s.set_timesteps(4)
+    B, h, w = 2, 12, 20
+    g = torch.Generator().manual_seed(3)
+    lat, eps, noise = (torch.randn(B, 4, h, w, generator=g) for _ in range(3))
+    for i in range(4):
+        ref, _ = s.step(eps, i, lat, noise)
+        coef = s.coefficients(i)
+        d = lat.to(DEV).clone()
+        ops.scheduler_step(eps.permute(0, 2, 3, 1).contiguous().to(DEV), d, noise.to(DEV), coef[:6], coef[6], B, h, w)
+        close(d, ref, rtol=1e-5, atol=1e-5, what=f"scheduler step {i}")
+    # classifier-free guidance variant
+    eu = torch.randn(B, 4, h, w, generator=g)
+    ref, _ = s.step(eu + 7.5 * (eps - eu), 1, lat, noise)
+    d = lat.to(DEV).clone()
+    coef = s.coefficients(1)
+    ops.scheduler_step(eps.permute(0, 2, 3, 1).contiguous().to(DEV), d, noise.to(DEV), coef[:6], coef[6], B, h, w,
+                       eps_uncond=eu.permute(0, 2, 3, 1).contiguous().to(DEV), guidance=7.5)
+    close(d, ref, rtol=1e-5, atol=2e-5, what="scheduler step cfg")
+    for hh, ww in ((64, 64), (96, 64), (8, 8), (12, 20)):
+        lt = torch.randn(1, 4, hh, ww, generator=g)
+        o = torch.empty(1, 4, 8, 8, dtype=torch.float16, device=DEV)
+        ops.latents_pool8(lt.to(DEV), o, 1, hh, ww)
+        assert o.cpu().numpy().tobytes() == glue.latents_blob(lt.numpy()) or \
+            np.abs(o.cpu().float().numpy() - np.frombuffer(glue.latents_blob(lt.numpy()), np.float16).reshape(1, 4, 8, 8).astype(np.float32)).max() < 2e-3
