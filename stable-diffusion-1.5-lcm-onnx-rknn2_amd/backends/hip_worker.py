@@ -1,0 +1,123 @@
+"""``HipLcmWorker`` -- the MI355X drop-in for the reference's ``DiffusersCudaWorker``
+(backends/cuda_worker.py:20-304): same constructor, attributes, ``run_job`` /
+``run_job_with_latents`` contract and error behaviour, with the arithmetic of
+``self.pipe(...)`` (cuda_worker.py:221-229) replaced by the hipGraph of HIP kernels in
+``pipeline.LcmHipPipeline``.
+
+Env (as the reference, backends/cuda_worker.py:43-61):
+  MODEL_ROOT, MODEL   checkpoint location (diffusers directory).  MODEL=synthetic (or
+                      LCM_HIP_SYNTHETIC=1) selects seeded synthetic weights of the SD1.5 architecture --
+                      no checkpoint ships with the reference.
+  CUDA_DEVICE / HIP_DEVICE   default cuda:0 (torch's name for the HIP device)
+  CUDA_DTYPE                 only fp16 is implemented on the HIP path (the reference's default)
+"""
+from __future__ import annotations
+
+import io
+import os
+from typing import Tuple
+
+import torch
+
+from ..lib import LcmHipError
+from ..pipeline import LcmHipPipeline
+from ..prompt import ClipPromptEncoder, SyntheticPromptEncoder
+from ..scheduler import LCMSchedule
+from .. import weights as _weights
+
+
+def parse_size(size) -> Tuple[int, int]:
+    try:
+        w_str, h_str = str(size).lower().split("x")
+        return int(w_str), int(h_str)
+    except Exception:
+        raise RuntimeError(f"Invalid size '{size}', expected 'WIDTHxHEIGHT'")     # cuda_worker.py:204-208
+
+
+def encode_png(rgb) -> bytes:
+    from PIL import Image
+    buf = io.BytesIO()
+    Image.fromarray(rgb).save(buf, format="PNG", compress_level=int(os.environ.get("LCM_PNG_COMPRESS", "6")))
+    return buf.getvalue()
+
+
+class HipLcmWorker:
+    def __init__(self, worker_id: int):
+        self.worker_id = worker_id
+        model_root = (os.environ.get("MODEL_ROOT") or "").strip()
+        model_name = (os.environ.get("MODEL") or "").strip()
+        synthetic = model_name == "synthetic" or os.environ.get("LCM_HIP_SYNTHETIC", "0").lower() in ("1", "true", "yes", "on")
+        if not synthetic:
+            if not model_root:
+                raise RuntimeError("MODEL_ROOT is required for BACKEND=hip")
+            if not model_name:
+                raise RuntimeError("MODEL is required for BACKEND=hip")
+        dtype_str = os.environ.get("CUDA_DTYPE", "fp16").lower().strip()
+        if dtype_str != "fp16":
+            raise RuntimeError(f"CUDA_DTYPE={dtype_str}: the HIP backend computes in fp16 (fp32 accumulate) only")
+        device = (os.environ.get("HIP_DEVICE") or os.environ.get("CUDA_DEVICE") or "cuda:0").strip()
+        if not torch.cuda.is_available():
+            raise LcmHipError("HipLcmWorker needs an MI355X; no CPU fallback exists on this path")
+        sched = LCMSchedule()
+        if synthetic:
+            usd, ucfg = _weights.synthetic_unet(), None
+            vsd, vcfg = _weights.synthetic_vae(), None
+            self._encode = SyntheticPromptEncoder()
+            ckpt = "synthetic"
+        else:
+            ckpt = os.path.join(model_root, model_name)
+            if not (os.path.isdir(ckpt) and os.path.exists(os.path.join(ckpt, "model_index.json"))):
+                raise RuntimeError(f"{ckpt}: the HIP backend loads diffusers-layout directories "
+                                   "(model_index.json); single-file checkpoints are not supported yet")
+            usd, ucfg, vsd, vcfg = _weights.load_diffusers_dir(ckpt)
+            if int(ucfg.get("cross_attention_dim", 768)) not in (768, 1024):
+                raise RuntimeError(f"cross_attention_dim={ucfg['cross_attention_dim']}: SDXL UNets are not "
+                                   "supported by the SD1.5 HIP worker")                # cuda_worker.py:114-116
+            sched = LCMSchedule.from_config_file(os.path.join(ckpt, "scheduler", "scheduler_config.json"))
+            self._encode = ClipPromptEncoder(ckpt, device)
+        self.pipe = LcmHipPipeline(usd, vsd, ucfg, vcfg, device=device, schedule=sched)
+        self.device = device
+        self.dtype = torch.float16
+        self._neg = None
+        print(f"[hip] worker {worker_id} loaded: {os.path.basename(ckpt)} on {device} dtype=fp16 "
+              f"unet={self.pipe.unet.weight_bytes() / 1e9:.2f}GB vae={self.pipe.vae.weight_bytes() / 1e9:.2f}GB")
+
+    # ------------------------------------------------------------------------------------------
+    def _generate(self, job):
+        req = job.req
+        width, height = parse_size(req.size)
+        seed = int(req.seed) if getattr(req, "seed", None) is not None else int(torch.randint(0, 100_000_000, (1,)).item())
+        sl = getattr(req, "style_lora", None)
+        level = int(getattr(sl, "level", 0) or 0) if sl else 0
+        if level > 0 and getattr(sl, "style", None):
+            # LoRA style adapters are a later row; requests run unstyled.
+            print(f"[hip] style_lora '{sl.style}' level {level} ignored (LoRA merge not implemented)")
+        pe = self._encode([req.prompt])
+        g = float(req.guidance_scale)
+        neg = None
+        if g > 1.0 and not self.pipe.unet.has_cond:
+            neg = self._encode([""])
+        out = self.pipe.generate(pe, [seed], width, height, int(req.num_inference_steps), g, negative_embeds=neg)
+        return out, seed
+
+    def run_job(self, job) -> Tuple[bytes, int]:
+        out, seed = self._generate(job)
+        return encode_png(out["rgb"][0]), seed
+
+    def run_job_with_latents(self, job) -> Tuple[bytes, int, bytes]:
+        # The reference re-runs the whole pipeline for the latents (cuda_worker.py:255-283); the sampler is
+        # deterministic in the seed, so the same pass's final latents are identical and are pooled on device.
+        out, seed = self._generate(job)
+        return encode_png(out["rgb"][0]), seed, out["pool8"][:1].tobytes(order="C")
+
+    def close(self):
+        pipe = getattr(self, "pipe", None)
+        if pipe is not None:
+            pipe.drop_plans()
+            self.pipe = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

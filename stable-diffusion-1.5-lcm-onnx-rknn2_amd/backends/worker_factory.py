@@ -1,0 +1,36 @@
+"""Factory usable as ``WorkerPool(worker_factory=create_hip_worker)`` (backends/worker_pool.py:147-181);
+mirrors ``create_cuda_worker`` / ``detect_worker_type`` (backends/worker_factory.py:17-100)."""
+from __future__ import annotations
+
+import json
+import os
+
+
+def detect_worker_type() -> str:
+    """cross_attention_dim -> 'sd15' | 'sdxl' (backends/worker_factory.py:55-67)."""
+    root = (os.environ.get("MODEL_ROOT") or "").strip()
+    name = (os.environ.get("MODEL") or "").strip()
+    if name == "synthetic":
+        return "sd15"
+    if not root:
+        raise RuntimeError("MODEL_ROOT environment variable is required")
+    if not name:
+        raise RuntimeError("MODEL environment variable is required")
+    cfgp = os.path.join(root, name, "unet", "config.json")
+    if not os.path.exists(cfgp):
+        raise RuntimeError(f"Model not found or not a diffusers directory: {os.path.join(root, name)}")
+    with open(cfgp) as f:
+        cad = json.load(f).get("cross_attention_dim")
+    if cad in (2048, 1280):
+        return "sdxl"
+    if cad in (768, 1024):
+        return "sd15"
+    raise RuntimeError(f"Unknown cross_attention_dim={cad}")
+
+
+def create_hip_worker(worker_id: int):
+    kind = detect_worker_type()
+    if kind != "sd15":
+        raise RuntimeError("SDXL checkpoints are not supported by the HIP backend yet")
+    from .hip_worker import HipLcmWorker
+    return HipLcmWorker(worker_id=worker_id)

@@ -1,0 +1,401 @@
+"""Host-side executors of the two networks on the hot path: they walk the UNet2DConditionModel /
+AutoencoderKL-decoder op graph (diffusers modules reached from
+backends/cuda_worker.py:221-229) and enqueue the HIP kernels of liblcmhip.so through ``ops``.
+
+No arithmetic happens here: Python only owns shapes, buffers and launch order; the whole sequence is
+captured once into a hipGraph by ``pipeline.LcmHipPipeline`` and replayed per request.
+
+Activations are pixel-major fp16 ``[B*H*W, C]``.  Buffers are allocated on first use and keyed by
+(role, shape), so every layer of a resolution level reuses the same few scratch tensors (they stay
+resident in the 256 MiB Infinity Cache); only skip connections get buffers of their own.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from .config import TEXT_SEQ_LEN, unet_config, vae_config
+from .packing import pack_conv1x1, pack_conv3x3, pack_geglu
+
+
+class _Buffers:
+    def __init__(self, device):
+        self.device = device
+        self._b = {}
+
+    def get(self, role, *shape, dtype=torch.float16):
+        key = (role, shape, dtype)
+        t = self._b.get(key)
+        if t is None:
+            t = torch.empty(shape, dtype=dtype, device=self.device)
+            self._b[key] = t
+        return t
+
+    def nbytes(self):
+        return sum(t.numel() * t.element_size() for t in self._b.values())
+
+
+def _dev(t, device, dtype=torch.float16):
+    return t.to(device=device, dtype=dtype).contiguous()
+
+
+class _Net:
+    def __init__(self, device):
+        self.device = device
+        self.w = {}
+        self.buf = _Buffers(device)
+        self._gn_ws = None
+
+    def _put(self, name, t, dtype=torch.float16):
+        self.w[name] = _dev(t, self.device, dtype)
+
+    def gn_ws(self, B, HW, C):
+        need = ops.groupnorm_ws_bytes(B, HW, C) // 4
+        if self._gn_ws is None or self._gn_ws.numel() < need:
+            self._gn_ws = torch.empty(max(need, 1 << 16), dtype=torch.float32, device=self.device)
+        return self._gn_ws
+
+    def weight_bytes(self):
+        return sum(t.numel() * t.element_size() for t in self.w.values())
+
+    # ---- shared blocks ----------------------------------------------------------------------
+    def _pack_resnet(self, sd, p, temb_list=None):
+        for n in ("norm1", "norm2"):
+            self._put(f"{p}.{n}.g", sd[f"{p}.{n}.weight"])
+            self._put(f"{p}.{n}.b", sd[f"{p}.{n}.bias"])
+        for n in ("conv1", "conv2"):
+            self._put(f"{p}.{n}.w", pack_conv3x3(sd[f"{p}.{n}.weight"]))
+            self._put(f"{p}.{n}.b", sd[f"{p}.{n}.bias"])
+        if f"{p}.conv_shortcut.weight" in sd:
+            self._put(f"{p}.sc.w", pack_conv1x1(sd[f"{p}.conv_shortcut.weight"]))
+            self._put(f"{p}.sc.b", sd[f"{p}.conv_shortcut.bias"])
+        if temb_list is not None:
+            temb_list.append((p, sd[f"{p}.time_emb_proj.weight"], sd[f"{p}.time_emb_proj.bias"]))
+
+    def resnet(self, p, x, C1, Cout, B, H, W, eps, x2=None, C2=0, rowadd=None, out_role="res_out"):
+        HW, M, Cin = H * W, B * H * W, C1 + C2
+        w = self.w
+        hn = self.buf.get("gn", M, Cin)
+        ops.groupnorm(x, w[p + ".norm1.g"], w[p + ".norm1.b"], hn, B, HW, C1, self.gn_ws(B, HW, Cin), x2=x2, C2=C2,
+                      eps=eps, silu=True)
+        h1 = self.buf.get("conv1", M, Cout)
+        ops.conv3x3(hn, w[p + ".conv1.w"], h1, B, H, W, Cin, Cout, bias=w[p + ".conv1.b"], rowadd=rowadd)
+        hn2 = self.buf.get("gn", M, Cout)
+        ops.groupnorm(h1, w[p + ".norm2.g"], w[p + ".norm2.b"], hn2, B, HW, Cout, self.gn_ws(B, HW, Cout), eps=eps,
+                      silu=True)
+        if (p + ".sc.w") in w:
+            sc = self.buf.get("shortcut", M, Cout)
+            ops.gemm(x, w[p + ".sc.w"], sc, bias=w[p + ".sc.b"], a2=x2)
+        else:
+            sc = x
+        out = self.buf.get(out_role, M, Cout)
+        ops.conv3x3(hn2, w[p + ".conv2.w"], out, B, H, W, Cout, Cout, bias=w[p + ".conv2.b"], res=sc)
+        return out
+
+
+# ==================================================================================================
+class UNetHip(_Net):
+    def __init__(self, sd: dict, cfg: dict | None = None, device="cuda"):
+        super().__init__(device)
+        self.cfg = cfg = unet_config(cfg)
+        boc = cfg["block_out_channels"]
+        self.heads = cfg["attention_head_dim"]
+        self.ctx_dim = cfg["cross_attention_dim"]
+        self.temb_dim = boc[0] * 4
+        nb = len(boc)
+        temb_list, kv_list = [], []
+        self._put("conv_in.w", pack_conv3x3(sd["conv_in.weight"]))
+        self._put("conv_in.b", sd["conv_in.bias"])
+        for n in ("linear_1", "linear_2"):
+            self._put(f"te.{n}.w", sd[f"time_embedding.{n}.weight"])
+            self._put(f"te.{n}.b", sd[f"time_embedding.{n}.bias"])
+        self.has_cond = bool(cfg.get("time_cond_proj_dim"))
+        if self.has_cond:
+            self._put("te.cond.w", sd["time_embedding.cond_proj.weight"])
+        for i in range(nb):
+            for j in range(cfg["layers_per_block"]):
+                self._pack_resnet(sd, f"down_blocks.{i}.resnets.{j}", temb_list)
+                if cfg["down_attn"][i]:
+                    self._pack_transformer(sd, f"down_blocks.{i}.attentions.{j}", kv_list)
+            if i < nb - 1:
+                p = f"down_blocks.{i}.downsamplers.0.conv"
+                self._put(p + ".w", pack_conv3x3(sd[p + ".weight"]))
+                self._put(p + ".b", sd[p + ".bias"])
+        self._pack_resnet(sd, "mid_block.resnets.0", temb_list)
+        self._pack_transformer(sd, "mid_block.attentions.0", kv_list)
+        self._pack_resnet(sd, "mid_block.resnets.1", temb_list)
+        up_attn = tuple(reversed(cfg["down_attn"]))
+        for i in range(nb):
+            for j in range(cfg["layers_per_block"] + 1):
+                self._pack_resnet(sd, f"up_blocks.{i}.resnets.{j}", temb_list)
+                if up_attn[i]:
+                    self._pack_transformer(sd, f"up_blocks.{i}.attentions.{j}", kv_list)
+            if i < nb - 1:
+                p = f"up_blocks.{i}.upsamplers.0.conv"
+                self._put(p + ".w", pack_conv3x3(sd[p + ".weight"]))
+                self._put(p + ".b", sd[p + ".bias"])
+        self._put("conv_norm_out.g", sd["conv_norm_out.weight"])
+        self._put("conv_norm_out.b", sd["conv_norm_out.bias"])
+        self._put("conv_out.w", pack_conv3x3(sd["conv_out.weight"]))
+        self._put("conv_out.b", sd["conv_out.bias"])
+        # all ResnetBlock2D.time_emb_proj stacked into one [sum(Cout), temb] matrix -> one launch per step
+        self.temb_off, off = {}, 0
+        for p, wt, bt in temb_list:
+            self.temb_off[p] = (off, wt.shape[0])
+            off += wt.shape[0]
+        self.temb_total = off
+        self._put("temb_all.w", torch.cat([t[1] for t in temb_list], 0))
+        self._put("temb_all.b", torch.cat([t[2] for t in temb_list], 0))
+        # all cross-attention to_k|to_v stacked into one [sum(2C), ctx] matrix -> one GEMM per request
+        self.kv_off, off = {}, 0
+        for p, wk, wv in kv_list:
+            self.kv_off[p] = (off, wk.shape[0])
+            off += 2 * wk.shape[0]
+        self.kv_total = off
+        self._put("kv_all.w", torch.cat([torch.cat([wk, wv], 0) for _, wk, wv in kv_list], 0))
+
+    def _pack_transformer(self, sd, p, kv_list):
+        t = p + ".transformer_blocks.0"
+        self._put(p + ".norm.g", sd[p + ".norm.weight"])
+        self._put(p + ".norm.b", sd[p + ".norm.bias"])
+        self._put(p + ".proj_in.w", pack_conv1x1(sd[p + ".proj_in.weight"]))
+        self._put(p + ".proj_in.b", sd[p + ".proj_in.bias"])
+        self._put(p + ".proj_out.w", pack_conv1x1(sd[p + ".proj_out.weight"]))
+        self._put(p + ".proj_out.b", sd[p + ".proj_out.bias"])
+        for n in ("norm1", "norm2", "norm3"):
+            self._put(f"{p}.{n}.g", sd[f"{t}.{n}.weight"])
+            self._put(f"{p}.{n}.b", sd[f"{t}.{n}.bias"])
+        self._put(p + ".qkv.w", torch.cat([sd[f"{t}.attn1.to_{n}.weight"] for n in "qkv"], 0))
+        self._put(p + ".o1.w", sd[f"{t}.attn1.to_out.0.weight"])
+        self._put(p + ".o1.b", sd[f"{t}.attn1.to_out.0.bias"])
+        self._put(p + ".q2.w", sd[f"{t}.attn2.to_q.weight"])
+        self._put(p + ".o2.w", sd[f"{t}.attn2.to_out.0.weight"])
+        self._put(p + ".o2.b", sd[f"{t}.attn2.to_out.0.bias"])
+        kv_list.append((p, sd[f"{t}.attn2.to_k.weight"], sd[f"{t}.attn2.to_v.weight"]))
+        wp, bp = pack_geglu(sd[f"{t}.ff.net.0.proj.weight"], sd[f"{t}.ff.net.0.proj.bias"])
+        self._put(p + ".ff1.w", wp)
+        self._put(p + ".ff1.b", bp)
+        self._put(p + ".ff2.w", sd[f"{t}.ff.net.2.weight"])
+        self._put(p + ".ff2.b", sd[f"{t}.ff.net.2.bias"])
+
+    # ---- per request: cross-attention K/V of all 16 layers (depend on the prompt only) -------
+    def encode_context(self, ehs, B):
+        """ehs: fp16 [B*77, ctx] -> kv_all [B*77, kv_total]."""
+        kv = self.buf.get("kv_all", B * TEXT_SEQ_LEN, self.kv_total)
+        ops.gemm(ehs, self.w["kv_all.w"], kv)
+        return kv
+
+    # ---- per step: time embedding MLP + all time_emb_proj (depend on t and guidance only) ----
+    def time_embed(self, t, wemb, B):
+        w = self.w
+        ch0 = self.cfg["block_out_channels"][0]
+        e0 = self.buf.get("te0", B, ch0)
+        ops.timestep_embedding(float(t), e0, B, ch0)
+        if self.has_cond and wemb is not None:
+            e1 = self.buf.get("te1", B, ch0)
+            ops.linear_smallm(wemb, w["te.cond.w"], e1, B, ch0, wemb.shape[1], res=e0)
+        else:
+            e1 = e0
+        h = self.buf.get("te_h", B, self.temb_dim)
+        ops.linear_smallm(e1, w["te.linear_1.w"], h, B, self.temb_dim, ch0, bias=w["te.linear_1.b"], silu_out=True)
+        temb = self.buf.get("temb", B, self.temb_dim)
+        ops.linear_smallm(h, w["te.linear_2.w"], temb, B, self.temb_dim, self.temb_dim, bias=w["te.linear_2.b"])
+        ta = self.buf.get("temb_all", B, self.temb_total)
+        ops.linear_smallm(temb, w["temb_all.w"], ta, B, self.temb_total, self.temb_dim, bias=w["temb_all.b"], silu_in=True)
+        return ta
+
+    def _res(self, p, x, C1, Cout, B, H, W, ta, x2=None, C2=0, out_role="res_out"):
+        off, n = self.temb_off[p]
+        return self.resnet(p, x, C1, Cout, B, H, W, self.cfg["norm_eps"], x2=x2, C2=C2, rowadd=ta[:, off:off + n],
+                           out_role=out_role)
+
+    def transformer(self, p, x, C, B, H, W, kv_all, out_role):
+        w, heads = self.w, self.heads
+        HW, M, d = H * W, B * H * W, C // heads
+        hn = self.buf.get("gn", M, C)
+        ops.groupnorm(x, w[p + ".norm.g"], w[p + ".norm.b"], hn, B, HW, C, self.gn_ws(B, HW, C), eps=1e-6, silu=False)
+        h = self.buf.get("tf_h", M, C)
+        ops.gemm(hn, w[p + ".proj_in.w"], h, bias=w[p + ".proj_in.b"])
+        n = self.buf.get("tf_ln", M, C)
+        ops.layernorm(h, w[p + ".norm1.g"], w[p + ".norm1.b"], n, M, C)
+        qkv = self.buf.get("tf_qkv", M, 3 * C)
+        ops.gemm(n, w[p + ".qkv.w"], qkv)
+        a = self.buf.get("tf_attn", M, C)
+        ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], a, B, heads, HW, HW, d, ldq=3 * C, ldk=3 * C,
+                      ldv=3 * C, ldo=C)
+        ops.gemm(a, w[p + ".o1.w"], h, bias=w[p + ".o1.b"], res=h)
+        ops.layernorm(h, w[p + ".norm2.g"], w[p + ".norm2.b"], n, M, C)
+        q2 = self.buf.get("tf_q2", M, C)
+        ops.gemm(n, w[p + ".q2.w"], q2)
+        off, _ = self.kv_off[p]
+        ops.attention(q2, kv_all[:, off:off + C], kv_all[:, off + C:off + 2 * C], a, B, heads, HW, TEXT_SEQ_LEN, d,
+                      ldq=C, ldk=self.kv_total, ldv=self.kv_total, ldo=C)
+        ops.gemm(a, w[p + ".o2.w"], h, bias=w[p + ".o2.b"], res=h)
+        ops.layernorm(h, w[p + ".norm3.g"], w[p + ".norm3.b"], n, M, C)
+        ff = self.buf.get("tf_ff", M, 4 * C)
+        ops.gemm(n, w[p + ".ff1.w"], ff, bias=w[p + ".ff1.b"], epilogue=1)
+        ops.gemm(ff, w[p + ".ff2.w"], h, bias=w[p + ".ff2.b"], res=h)
+        out = self.buf.get(out_role, M, C)
+        ops.gemm(h, w[p + ".proj_out.w"], out, bias=w[p + ".proj_out.b"], res=x)
+        return out
+
+    def forward(self, lat, t, kv_all, wemb, B, h, w_, eps_out, taps=None):
+        """lat fp32 [B,4,h,w] -> eps_out fp32 [B,h,w,4] (pixel-major)."""
+        cfg, wt = self.cfg, self.w
+        boc = cfg["block_out_channels"]
+        nb = len(boc)
+        ta = self.time_embed(t, wemb, B)
+        H, W = h, w_
+        x = self.buf.get("skip0", B * H * W, boc[0])
+        ops.conv3x3_c4(lat, wt["conv_in.w"], x, B, H, W, boc[0], bias=wt["conv_in.b"])
+        skips = [(x, boc[0])]
+        ch, ns = boc[0], 1
+
+        def tap(name, t_, C, H_, W_):
+            if taps is not None:
+                taps[name] = t_.reshape(B, H_, W_, C).permute(0, 3, 1, 2).float().cpu()
+
+        tap("conv_in", x, ch, H, W)
+        for i in range(nb):
+            for j in range(cfg["layers_per_block"]):
+                p = f"down_blocks.{i}.resnets.{j}"
+                attn = cfg["down_attn"][i]
+                x = self._res(p, x, ch, boc[i], B, H, W, ta, out_role="res_out" if attn else f"skip{ns}")
+                ch = boc[i]
+                tap(p, x, ch, H, W)
+                if attn:
+                    p = f"down_blocks.{i}.attentions.{j}"
+                    x = self.transformer(p, x, ch, B, H, W, kv_all, f"skip{ns}")
+                    tap(p, x, ch, H, W)
+                skips.append((x, ch))
+                ns += 1
+            if i < nb - 1:
+                p = f"down_blocks.{i}.downsamplers.0.conv"
+                y = self.buf.get(f"skip{ns}", B * (H // 2) * (W // 2), ch)
+                ops.conv3x3(x, wt[p + ".w"], y, B, H, W, ch, ch, bias=wt[p + ".b"], stride=2)
+                H, W, x = H // 2, W // 2, y
+                skips.append((x, ch))
+                ns += 1
+        x = self._res("mid_block.resnets.0", x, ch, ch, B, H, W, ta)
+        x = self.transformer("mid_block.attentions.0", x, ch, B, H, W, kv_all, "tf_out")
+        x = self._res("mid_block.resnets.1", x, ch, ch, B, H, W, ta, out_role="cur")
+        tap("mid_block.resnets.1", x, ch, H, W)
+        rboc = tuple(reversed(boc))
+        up_attn = tuple(reversed(cfg["down_attn"]))
+        for i in range(nb):
+            for j in range(cfg["layers_per_block"] + 1):
+                s, sc = skips.pop()
+                p = f"up_blocks.{i}.resnets.{j}"
+                x = self._res(p, x, ch, rboc[i], B, H, W, ta, x2=s, C2=sc, out_role="res_out" if up_attn[i] else "cur")
+                ch = rboc[i]
+                tap(p, x, ch, H, W)
+                if up_attn[i]:
+                    p = f"up_blocks.{i}.attentions.{j}"
+                    x = self.transformer(p, x, ch, B, H, W, kv_all, "cur")
+                    tap(p, x, ch, H, W)
+            if i < nb - 1:
+                p = f"up_blocks.{i}.upsamplers.0.conv"
+                y = self.buf.get("ups", B * 4 * H * W, ch)
+                ops.conv3x3(x, wt[p + ".w"], y, B, H, W, ch, ch, bias=wt[p + ".b"], ups=1)
+                H, W, x = 2 * H, 2 * W, y
+                tap(f"up_blocks.{i}.upsamplers.0", x, ch, H, W)
+        hn = self.buf.get("gn", B * H * W, ch)
+        ops.groupnorm(x, wt["conv_norm_out.g"], wt["conv_norm_out.b"], hn, B, H * W, ch, self.gn_ws(B, H * W, ch),
+                      eps=cfg["norm_eps"], silu=True)
+        ops.conv3x3_smalln(hn, wt["conv_out.w"], eps_out, B, H, W, ch, cfg["out_channels"], bias=wt["conv_out.b"], mode=0)
+        return eps_out
+
+
+# ==================================================================================================
+class VAEDecoderHip(_Net):
+    def __init__(self, sd: dict, cfg: dict | None = None, device="cuda"):
+        super().__init__(device)
+        self.cfg = cfg = vae_config(cfg)
+        boc = cfg["block_out_channels"]
+        self._put("pq.w", sd["post_quant_conv.weight"].reshape(4, 4), torch.float32)
+        self._put("pq.b", sd["post_quant_conv.bias"], torch.float32)
+        self._put("conv_in.w", pack_conv3x3(sd["decoder.conv_in.weight"]))
+        self._put("conv_in.b", sd["decoder.conv_in.bias"])
+        self._pack_resnet(sd, "decoder.mid_block.resnets.0")
+        self._pack_resnet(sd, "decoder.mid_block.resnets.1")
+        a = "decoder.mid_block.attentions.0"
+        self._put("attn.norm.g", sd[a + ".group_norm.weight"])
+        self._put("attn.norm.b", sd[a + ".group_norm.bias"])
+        for n in ("to_q", "to_k", "to_v"):
+            self._put(f"attn.{n}.w", sd[f"{a}.{n}.weight"].reshape(boc[-1], boc[-1]))
+            self._put(f"attn.{n}.b", sd[f"{a}.{n}.bias"])
+        self._put("attn.o.w", sd[a + ".to_out.0.weight"].reshape(boc[-1], boc[-1]))
+        self._put("attn.o.b", sd[a + ".to_out.0.bias"])
+        nb = len(boc)
+        for i in range(nb):
+            for j in range(cfg["layers_per_block"] + 1):
+                self._pack_resnet(sd, f"decoder.up_blocks.{i}.resnets.{j}")
+            if i < nb - 1:
+                p = f"decoder.up_blocks.{i}.upsamplers.0.conv"
+                self._put(p + ".w", pack_conv3x3(sd[p + ".weight"]))
+                self._put(p + ".b", sd[p + ".bias"])
+        self._put("norm_out.g", sd["decoder.conv_norm_out.weight"])
+        self._put("norm_out.b", sd["decoder.conv_norm_out.bias"])
+        self._put("conv_out.w", pack_conv3x3(sd["decoder.conv_out.weight"]))
+        self._put("conv_out.b", sd["decoder.conv_out.bias"])
+
+    def mid_attention(self, x, C, B, H, W):
+        w = self.w
+        S, M = H * W, B * H * W
+        hn = self.buf.get("gn", M, C)
+        ops.groupnorm(x, w["attn.norm.g"], w["attn.norm.b"], hn, B, S, C, self.gn_ws(B, S, C), eps=1e-6, silu=False)
+        q, k, v = (self.buf.get(f"attn_{n}", M, C) for n in "qkv")
+        for n, t in (("to_q", q), ("to_k", k), ("to_v", v)):
+            ops.gemm(hn, w[f"attn.{n}.w"], t, bias=w[f"attn.{n}.b"])
+        sc = self.buf.get("attn_scores", B * S, S)
+        ops.gemm(q, k, sc, M=S, N=S, K=C, lda=C, ldo=S, batch=B, strideA=S * C, strideW=S * C, strideO=S * S,
+                 out_scale=C ** -0.5)
+        ops.softmax_rows(sc, B * S, S, S)
+        vt = self.buf.get("attn_vt", B * C, S)
+        ops.transpose(v, vt, S, C, ldi=C, ldo=S, batch=B, stride_in=S * C, stride_out=C * S)
+        o = self.buf.get("attn_o", M, C)
+        ops.gemm(sc, vt, o, M=S, N=C, K=S, lda=S, ldo=C, batch=B, strideA=S * S, strideW=C * S, strideO=S * C)
+        out = self.buf.get("res_out2", M, C)
+        ops.gemm(o, w["attn.o.w"], out, bias=w["attn.o.b"], res=x)
+        return out
+
+    def decode(self, lat, B, h, w_, rgb_out, img_f32=None, taps=None):
+        """lat fp32 [B,4,h,w] (UNet space) -> rgb_out u8 [B,8h,8w,3]; optional fp32 NHWC image copy."""
+        cfg, wt = self.cfg, self.w
+        boc = cfg["block_out_channels"]
+        H, W = h, w_
+        ch = boc[-1]
+
+        def tap(name, t_, C, H_, W_):
+            if taps is not None:
+                taps[name] = t_.reshape(B, H_, W_, C).permute(0, 3, 1, 2).float().cpu()
+
+        x = self.buf.get("cur", B * H * W, ch)
+        ops.conv3x3_c4(lat, wt["conv_in.w"], x, B, H, W, ch, bias=wt["conv_in.b"], pre_w=wt["pq.w"], pre_b=wt["pq.b"],
+                       in_scale=1.0 / cfg["scaling_factor"])
+        tap("decoder.conv_in", x, ch, H, W)
+        x = self.resnet("decoder.mid_block.resnets.0", x, ch, ch, B, H, W, 1e-6)
+        tap("decoder.mid_block.resnets.0", x, ch, H, W)
+        x = self.mid_attention(x, ch, B, H, W)
+        tap("decoder.mid_block.attentions.0", x, ch, H, W)
+        x = self.resnet("decoder.mid_block.resnets.1", x, ch, ch, B, H, W, 1e-6, out_role="cur")
+        rboc = tuple(reversed(boc))
+        nb = len(boc)
+        roles = ("res_out", "cur")
+        for i in range(nb):
+            for j in range(cfg["layers_per_block"] + 1):
+                p = f"decoder.up_blocks.{i}.resnets.{j}"
+                x = self.resnet(p, x, ch, rboc[i], B, H, W, 1e-6, out_role=roles[j & 1])
+                ch = rboc[i]
+                tap(p, x, ch, H, W)
+            if i < nb - 1:
+                p = f"decoder.up_blocks.{i}.upsamplers.0.conv"
+                y = self.buf.get("ups", B * 4 * H * W, ch)
+                ops.conv3x3(x, wt[p + ".w"], y, B, H, W, ch, ch, bias=wt[p + ".b"], ups=1)
+                H, W, x = 2 * H, 2 * W, y
+                tap(f"decoder.up_blocks.{i}.upsamplers.0", x, ch, H, W)
+        hn = self.buf.get("gn", B * H * W, ch)
+        ops.groupnorm(x, wt["norm_out.g"], wt["norm_out.b"], hn, B, H * W, ch, self.gn_ws(B, H * W, ch), eps=1e-6, silu=True)
+        ops.conv3x3_smalln(hn, wt["conv_out.w"], rgb_out, B, H, W, ch, cfg["out_channels"], bias=wt["conv_out.b"], mode=1,
+                           out_f32=img_f32)
+        return rgb_out

@@ -1,0 +1,196 @@
+"""The LCM sampler on the MI355X: the arithmetic under ``self.pipe(...)`` (backends/cuda_worker.py:221-229)
+as one hipGraph of hand-written HIP kernels.
+
+Per request batch: prompt embeddings [B,77,768] + per-request seeds -> uint8 RGB [B,H,W,3] (+ final latents).
+Order of operations follows backends/rknnlcm.py:450-647 (prompt embeds -> guidance embedding -> timesteps ->
+latents from the request's generator -> [UNet -> LCMScheduler.step] x n -> /scaling_factor -> VAE -> u8).
+
+RNG contract: each request owns a CPU ``torch.Generator`` seeded with its seed; draws are
+latents[1,4,h,w] then one noise tensor per non-final step.  All draws happen on the host BEFORE the graph is
+launched, so the captured graph is RNG-free and replays for any seed.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import ops
+from .config import TEXT_SEQ_LEN, VAE_SCALE_FACTOR
+from .lib import LcmHipError
+from .model import UNetHip, VAEDecoderHip
+from .scheduler import LCMSchedule
+
+
+def guidance_scale_embedding(w: np.ndarray, dim: int) -> np.ndarray:
+    """w = guidance_scale - 1 per request (backends/rknnlcm.py:572, :651-677)."""
+    w = np.asarray(w, dtype=np.float32) * 1000
+    half = dim // 2
+    f = np.exp(np.arange(half, dtype=np.float32) * -(np.log(10000.0) / (half - 1)))
+    e = w[:, None] * f[None, :]
+    e = np.concatenate([np.sin(e), np.cos(e)], axis=1)
+    if dim % 2 == 1:
+        e = np.pad(e, [(0, 0), (0, 1)])
+    return e.astype(np.float32)
+
+
+def draw_noise(seed: int, h: int, w: int, n_extra: int, sigma: float = 1.0):
+    g = torch.Generator(device="cpu").manual_seed(int(seed))
+    shape = (1, 4, h, w)
+    lat = torch.randn(shape, generator=g, dtype=torch.float32) * sigma
+    extra = [torch.randn(shape, generator=g, dtype=torch.float32) for _ in range(n_extra)]
+    return lat, extra
+
+
+class _Plan:
+    """Buffers + captured graph for one (B, h, w, steps, cfg) key."""
+
+    def __init__(self, pipe, B, h, w, steps, do_cfg):
+        dev = pipe.device
+        self.B, self.h, self.w, self.steps, self.do_cfg = B, h, w, steps, do_cfg
+        UB = 2 * B if do_cfg else B
+        self.UB = UB
+        self.ehs = torch.zeros(UB * TEXT_SEQ_LEN, pipe.unet.ctx_dim, dtype=torch.float16, device=dev)
+        self.wemb = torch.zeros(UB, pipe.unet.cfg.get("time_cond_proj_dim") or 8, dtype=torch.float16, device=dev)
+        self.lat0 = torch.zeros(B, 4, h, w, dtype=torch.float32, device=dev)         # request input
+        self.lat = torch.zeros(UB, 4, h, w, dtype=torch.float32, device=dev)          # sampler state
+        self.noise = torch.zeros(max(steps - 1, 1), B, 4, h, w, dtype=torch.float32, device=dev)
+        self.eps = torch.zeros(UB, h, w, 4, dtype=torch.float32, device=dev)
+        self.rgb = torch.zeros(B, h * VAE_SCALE_FACTOR, w * VAE_SCALE_FACTOR, 3, dtype=torch.uint8, device=dev)
+        self.pool8 = torch.zeros(B, 4, 8, 8, dtype=torch.float16, device=dev)
+        self.img_f32 = None
+        self.guidance = 1.0
+        self.graph = None
+        # pinned staging for H2D / D2H
+        self.h_lat = torch.zeros(B, 4, h, w, dtype=torch.float32).pin_memory()
+        self.h_noise = torch.zeros(max(steps - 1, 1), B, 4, h, w, dtype=torch.float32).pin_memory()
+        self.h_rgb = torch.zeros(B, h * VAE_SCALE_FACTOR, w * VAE_SCALE_FACTOR, 3, dtype=torch.uint8).pin_memory()
+        self.h_pool8 = torch.zeros(B, 4, 8, 8, dtype=torch.float16).pin_memory()
+        self.h_latout = torch.zeros(B, 4, h, w, dtype=torch.float32).pin_memory()
+
+
+class LcmHipPipeline:
+    def __init__(self, unet_sd, vae_sd, unet_cfg=None, vae_cfg=None, device="cuda:0", schedule: LCMSchedule | None = None,
+                 use_graph=True):
+        if not torch.cuda.is_available():
+            raise LcmHipError("LcmHipPipeline needs an MI355X (torch.cuda.is_available() is False); "
+                              "there is no CPU fallback on the product path")
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        self.unet = UNetHip(unet_sd, unet_cfg, self.device)
+        self.vae = VAEDecoderHip(vae_sd, vae_cfg, self.device)
+        self.sched = schedule or LCMSchedule()
+        self.use_graph = use_graph
+        self._plans = {}
+        self.stream = torch.cuda.Stream(device=self.device)
+
+    # ------------------------------------------------------------------------------------------
+    def _enqueue(self, P: _Plan, guidance: float, want_float=False, taps=None):
+        """Enqueue the whole sampler on the current stream (this is what gets captured)."""
+        B, UB, h, w = P.B, P.UB, P.h, P.w
+        ts = self.sched.timesteps(P.steps)
+        if P.do_cfg:
+            P.lat[:B].copy_(P.lat0)
+            P.lat[B:].copy_(P.lat0)
+        else:
+            P.lat.copy_(P.lat0)
+        kv = self.unet.encode_context(P.ehs, UB)
+        wemb = P.wemb if self.unet.has_cond else None
+        for i, t in enumerate(ts):
+            self.unet.forward(P.lat, int(t), kv, wemb, UB, h, w, P.eps, taps=taps if i == 0 else None)
+            coef, last = self.sched.step_coefficients(ts, i)
+            noise = P.noise[min(i, P.noise.shape[0] - 1)]
+            if P.do_cfg:   # rows [0,B) = negative prompt, [B,2B) = prompt
+                ops.scheduler_step(P.eps[B:], P.lat[B:], noise, coef, last, B, h, w, eps_uncond=P.eps[:B], guidance=guidance)
+                P.lat[:B].copy_(P.lat[B:])
+            else:
+                ops.scheduler_step(P.eps, P.lat, noise, coef, last, B, h, w)
+        final = P.lat[B:] if P.do_cfg else P.lat
+        ops.latents_pool8(final, P.pool8, B, h, w)
+        if want_float and P.img_f32 is None:
+            P.img_f32 = torch.zeros(B, h * 8, w * 8, 3, dtype=torch.float32, device=self.device)
+        self.vae.decode(final, B, h, w, P.rgb, img_f32=P.img_f32 if want_float else None, taps=taps)
+        return final
+
+    def plan(self, B, h, w, steps, do_cfg=False) -> _Plan:
+        key = (B, h, w, steps, do_cfg)
+        P = self._plans.get(key)
+        if P is None:
+            P = _Plan(self, B, h, w, steps, do_cfg)
+            self._plans[key] = P
+        return P
+
+    def drop_plans(self):
+        for P in self._plans.values():
+            if P.graph is not None:
+                P.graph.close()
+        self._plans.clear()
+
+    # ------------------------------------------------------------------------------------------
+    @torch.inference_mode()
+    def generate(self, prompt_embeds, seeds, width, height, steps, guidance_scale=1.0, negative_embeds=None,
+                 want_float=False, taps=None, latents=None):
+        """prompt_embeds: [B,77,ctx] (any float dtype, host or device); seeds: B ints.
+        Returns dict(rgb uint8 [B,H,W,3] (host), latents fp32 [B,4,h,w] (host), pool8 fp16 [B,4,8,8] (host))."""
+        pe = torch.as_tensor(prompt_embeds)
+        B = pe.shape[0]
+        if width % 64 or height % 64 or width <= 0 or height <= 0:
+            raise LcmHipError(f"unsupported size {width}x{height}: the HIP backend needs multiples of 64")
+        h, w = height // VAE_SCALE_FACTOR, width // VAE_SCALE_FACTOR
+        steps = int(steps)
+        has_cond = self.unet.has_cond
+        do_cfg = (guidance_scale > 1.0) and not has_cond
+        if do_cfg and negative_embeds is None:
+            raise LcmHipError("classifier-free guidance needs negative_embeds")
+        P = self.plan(B, h, w, steps, do_cfg)
+        with torch.cuda.stream(self.stream):
+            # ---- host-side request state -> device (outside the graph) ----
+            for b, s in enumerate(seeds):
+                if latents is not None:
+                    P.h_lat[b].copy_(torch.as_tensor(latents[b]).reshape(4, h, w))
+                    extra = []
+                else:
+                    l0, extra = draw_noise(s, h, w, steps - 1, self.sched.init_noise_sigma)
+                    P.h_lat[b].copy_(l0[0])
+                for i, n in enumerate(extra):
+                    P.h_noise[i, b].copy_(n[0])
+            P.lat0.copy_(P.h_lat, non_blocking=True)
+            P.noise.copy_(P.h_noise, non_blocking=True)
+            pe16 = pe.to(torch.float16).reshape(B * TEXT_SEQ_LEN, -1)
+            if do_cfg:
+                ne16 = torch.as_tensor(negative_embeds).to(torch.float16).reshape(B * TEXT_SEQ_LEN, -1)
+                P.ehs[:B * TEXT_SEQ_LEN].copy_(ne16, non_blocking=True)
+                P.ehs[B * TEXT_SEQ_LEN:].copy_(pe16, non_blocking=True)
+            else:
+                P.ehs.copy_(pe16, non_blocking=True)
+            if has_cond:
+                gs = np.full((B,), float(guidance_scale) - 1.0, dtype=np.float32)
+                P.wemb.copy_(torch.from_numpy(guidance_scale_embedding(gs, P.wemb.shape[1])).to(torch.float16),
+                             non_blocking=True)
+            # ---- the sampler: eager once (allocates scratch), then captured + replayed ----
+            eager = (not self.use_graph) or taps is not None or want_float or do_cfg
+            if eager:
+                final = self._enqueue(P, guidance_scale, want_float=want_float, taps=taps)
+            else:
+                if P.graph is None:
+                    self._enqueue(P, guidance_scale)           # warm-up: allocates every scratch buffer
+                    self.stream.synchronize()
+                    g = ops.Graph()
+                    with g:
+                        self._enqueue(P, guidance_scale)
+                    P.graph = g
+                P.graph.launch()
+                final = P.lat
+            P.h_rgb.copy_(P.rgb, non_blocking=True)
+            P.h_pool8.copy_(P.pool8, non_blocking=True)
+            P.h_latout.copy_(final, non_blocking=True)
+            self.stream.synchronize()
+        out = dict(rgb=P.h_rgb.numpy().copy(), latents=P.h_latout.numpy().copy(), pool8=P.h_pool8.numpy().copy())
+        if want_float:
+            out["image"] = P.img_f32.cpu().numpy()   # NHWC float, pre-clamp
+        return out
+
+    # hot loop only (device resident inputs already in the plan): used by bench.py
+    def replay(self, P: _Plan):
+        if P.graph is None:
+            raise LcmHipError("plan has no captured graph")
+        P.graph.launch()

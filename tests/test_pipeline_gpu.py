@@ -1,0 +1,142 @@
+"""Parity of the assembled HIP path against the CPU oracle (oracle/) on identical seeded inputs.
+
+Tolerance: BASELINE.json north_star -- per-pixel |delta| < 1e-2 on the decoded image in [0,1]
+(fp16 MI355X path vs fp32 CPU restatement).  Weights are the seeded synthetic SD1.5-architecture
+weights (no checkpoint ships with the reference), stored as fp16 and shared by both sides.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def state():
+    from sdlcm_amd import weights
+    from sdlcm_amd.pipeline import LcmHipPipeline
+    from oracle.pipeline import LCMPipelineOracle
+    usd, vsd = weights.synthetic_unet(), weights.synthetic_vae()
+    hip = LcmHipPipeline(usd, vsd, device="cuda:0")
+    ora = LCMPipelineOracle(usd, vsd)
+    return dict(hip=hip, ora=ora)
+
+
+def _embeds(B, seed=5):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(B, 77, 768, generator=g).to(torch.float16)
+
+
+def _report(tag, got, ref):
+    err = np.abs(got - ref)
+    print(f"[parity] {tag}: max|d|={err.max():.4g} mean|d|={err.mean():.4g} ref_rms={np.sqrt((ref ** 2).mean()):.4g}")
+    return err
+
+
+def test_unet_forward_parity(state):
+    from sdlcm_amd.pipeline import guidance_scale_embedding
+    hip, ora = state["hip"], state["ora"]
+    B, h, w, t = 2, 16, 16, 759
+    g = torch.Generator().manual_seed(11)
+    lat = torch.randn(B, 4, h, w, generator=g)
+    pe = _embeds(B)
+    wemb = torch.from_numpy(guidance_scale_embedding(np.zeros(B, np.float32), 256))
+    ora.unet.taps = {}
+    ref = ora.unet.forward(lat, t, pe.float(), wemb).numpy()
+    ref_taps, ora.unet.taps = ora.unet.taps, None
+    u = hip.unet
+    taps = {}
+    with torch.cuda.stream(hip.stream):
+        ehs = pe.reshape(B * 77, 768).to(hip.device)
+        kv = u.encode_context(ehs, B)
+        eps = torch.zeros(B, h, w, 4, dtype=torch.float32, device=hip.device)
+        u.forward(lat.to(hip.device), t, kv, wemb.to(hip.device, torch.float16), B, h, w, eps, taps=taps)
+        hip.stream.synchronize()
+    for k in ("conv_in", "down_blocks.0.resnets.0", "down_blocks.0.attentions.0", "down_blocks.2.attentions.1",
+              "mid_block.resnets.1", "up_blocks.1.attentions.2", "up_blocks.3.attentions.2"):
+        e = _report(k, taps[k].numpy(), ref_taps[k].numpy())
+        assert e.max() < 0.05 * max(1.0, np.abs(ref_taps[k].numpy()).max()), k
+    got = eps.cpu().numpy().transpose(0, 3, 1, 2)
+    e = _report("unet eps", got, ref)
+    assert e.max() < 2e-2
+
+
+def test_vae_decode_parity(state):
+    hip, ora = state["hip"], state["ora"]
+    B, h, w = 2, 16, 16
+    lat = torch.randn(B, 4, h, w, generator=torch.Generator().manual_seed(3)) * 0.9
+    ref = ora.vae.decode(lat).numpy()
+    with torch.cuda.stream(hip.stream):
+        rgb = torch.zeros(B, 8 * h, 8 * w, 3, dtype=torch.uint8, device=hip.device)
+        img = torch.zeros(B, 8 * h, 8 * w, 3, dtype=torch.float32, device=hip.device)
+        hip.vae.decode(lat.to(hip.device), B, h, w, rgb, img_f32=img)
+        hip.stream.synchronize()
+    got = img.cpu().numpy().transpose(0, 3, 1, 2)
+    e = _report("vae image", np.clip(got / 2 + 0.5, 0, 1), np.clip(ref / 2 + 0.5, 0, 1))
+    assert e.max() < 1e-2
+    from oracle import glue
+    u8 = glue.postprocess_u8(ref)
+    assert np.abs(rgb.cpu().numpy().astype(int) - u8.astype(int)).max() <= 3
+
+
+@pytest.mark.parametrize("size,steps,seed", [(128, 4, 42), (64, 1, 7), (192, 2, 1234)])
+def test_end_to_end_parity(state, size, steps, seed):
+    hip, ora = state["hip"], state["ora"]
+    pe = _embeds(1, seed=seed)
+    ref = ora(pe.float(), size, size, steps, 1.0, seed)
+    out = hip.generate(pe, [seed], size, size, steps, 1.0, want_float=True)
+    _report(f"{size}px latents", out["latents"], ref["latents"])
+    a = np.clip(out["image"].transpose(0, 3, 1, 2) / 2 + 0.5, 0, 1)
+    b = np.clip(ref["image"] / 2 + 0.5, 0, 1)
+    e = _report(f"{size}px {steps}-step image[0,1]", a, b)
+    assert e.max() < 1e-2
+    d8 = np.abs(out["rgb"].astype(int) - ref["image_u8"].astype(int))
+    print(f"[parity] u8 max diff {d8.max()}, differing pixels {(d8 > 0).mean():.4f}")
+    assert d8.max() <= 3
+
+
+def test_graph_replay_equals_eager_and_is_deterministic(state):
+    hip = state["hip"]
+    pe = _embeds(1, seed=9)
+    eager = hip.generate(pe, [77], 128, 128, 4, 1.0, want_float=True)
+    g1 = hip.generate(pe, [77], 128, 128, 4, 1.0)
+    g2 = hip.generate(pe, [77], 128, 128, 4, 1.0)
+    assert hip.plan(1, 16, 16, 4).graph is not None
+    assert np.array_equal(g1["rgb"], g2["rgb"]) and np.array_equal(g1["latents"], g2["latents"])
+    assert np.array_equal(g1["rgb"], eager["rgb"])
+    other = hip.generate(pe, [78], 128, 128, 4, 1.0)
+    assert not np.array_equal(other["rgb"], g1["rgb"])
+
+
+def test_batched_requests_match_single_requests(state):
+    hip = state["hip"]
+    pe = _embeds(3, seed=21)
+    seeds = [1000, 1001, 1002]
+    batched = hip.generate(pe, seeds, 128, 128, 4, 1.0)
+    for i, s in enumerate(seeds):
+        one = hip.generate(pe[i:i + 1], [s], 128, 128, 4, 1.0)
+        assert np.array_equal(one["rgb"][0], batched["rgb"][i]), f"request {i} differs in the batch"
+
+
+def test_latents_blob_matches_oracle_pooling(state):
+    from oracle import glue
+    hip = state["hip"]
+    out = hip.generate(_embeds(1), [5], 128, 128, 2, 1.0)
+    blob = out["pool8"][:1].tobytes(order="C")
+    assert len(blob) == 512
+    ref = np.frombuffer(glue.latents_blob(out["latents"][:1]), np.float16)
+    assert np.abs(np.frombuffer(blob, np.float16).astype(np.float32) - ref.astype(np.float32)).max() < 2e-2
+
+
+def test_full_size_parity_512(state):
+    """BASELINE config 2 shape: 512x512, 4 steps, batch 1 -- the north_star tolerance at full size."""
+    hip, ora = state["hip"], state["ora"]
+    pe = _embeds(1, seed=42)
+    ref = ora(pe.float(), 512, 512, 4, 1.0, 42)
+    out = hip.generate(pe, [42], 512, 512, 4, 1.0, want_float=True)
+    a = np.clip(out["image"].transpose(0, 3, 1, 2) / 2 + 0.5, 0, 1)
+    b = np.clip(ref["image"] / 2 + 0.5, 0, 1)
+    e = _report("512px 4-step image[0,1]", a, b)
+    assert e.max() < 1e-2

@@ -1,0 +1,87 @@
+"""Behavioural contract of the worker, mirroring the reference's only live-GPU suite
+(tests/test_sdxl_worker.py:118-298): attrs, (bytes,int) result, PNG magic, seed echo, same seed =>
+identical bytes, 512-byte latents blob, size sweep, invalid size error, seed=None => fresh seeds."""
+import os
+from dataclasses import dataclass, field
+from typing import Optional
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@dataclass
+class MockStyleLora:
+    style: Optional[str] = None
+    level: int = 0
+
+
+@dataclass
+class MockGenerateRequest:
+    prompt: str
+    size: str = "512x512"
+    num_inference_steps: int = 4
+    guidance_scale: float = 1.0
+    seed: Optional[int] = None
+    style_lora: MockStyleLora = field(default_factory=MockStyleLora)
+
+
+@dataclass
+class MockJob:
+    req: MockGenerateRequest
+
+
+@pytest.fixture(scope="module")
+def worker():
+    os.environ["MODEL"] = "synthetic"
+    os.environ.setdefault("MODEL_ROOT", "/nonexistent")
+    from sdlcm_amd.backends.worker_factory import create_hip_worker
+    w = create_hip_worker(worker_id=0)
+    yield w
+    w.close()
+
+
+def test_attrs(worker):
+    assert worker.worker_id == 0
+    assert hasattr(worker, "pipe") and hasattr(worker, "device") and hasattr(worker, "dtype")
+
+
+def test_run_job_basic_and_deterministic(worker):
+    job = MockJob(MockGenerateRequest(prompt="a beautiful mountain landscape at sunset", size="256x256", seed=12345))
+    png, seed = worker.run_job(job)
+    assert isinstance(png, bytes) and isinstance(seed, int) and seed == 12345
+    assert png[:8] == b"\x89PNG\r\n\x1a\n" and len(png) > 1000
+    png2, seed2 = worker.run_job(job)
+    assert png2 == png and seed2 == seed
+
+
+def test_latents_blob(worker):
+    job = MockJob(MockGenerateRequest(prompt="a serene lake", size="256x256", seed=99999))
+    png, seed, lat = worker.run_job_with_latents(job)
+    assert png[:8] == b"\x89PNG\r\n\x1a\n" and seed == 99999 and len(lat) == 512
+
+
+@pytest.mark.parametrize("size", ["64x64", "512x512", "768x512"])
+def test_sizes(worker, size):
+    from PIL import Image
+    import io
+    steps, g = (1, 0.0) if size == "64x64" else (4, 1.0)     # yume/dream_worker.py:218-226
+    png, _ = worker.run_job(MockJob(MockGenerateRequest(prompt="p", size=size, seed=42, num_inference_steps=steps,
+                                                        guidance_scale=g)))
+    w, h = (int(v) for v in size.split("x"))
+    assert Image.open(io.BytesIO(png)).size == (w, h)
+
+
+def test_invalid_size(worker):
+    with pytest.raises(RuntimeError, match="Invalid size"):
+        worker.run_job(MockJob(MockGenerateRequest(prompt="test", size="invalid", seed=42)))
+    # the worker stays usable afterwards
+    png, _ = worker.run_job(MockJob(MockGenerateRequest(prompt="test", size="128x128", seed=42)))
+    assert png[:4] == b"\x89PNG"
+
+
+def test_random_seed(worker):
+    job = MockJob(MockGenerateRequest(prompt="a random test image", size="128x128", seed=None))
+    p1, s1 = worker.run_job(job)
+    p2, s2 = worker.run_job(job)
+    assert 0 <= s1 < 100_000_000 and 0 <= s2 < 100_000_000 and s1 != s2 and p1 != p2
