@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""Headline benchmark: 512x512 4-step LCM images/sec on N MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one pass of the hot path over one batch: a full 4-step LCM sample (4 x UNet + scheduler steps +
+VAE decode to RGB8) replayed from the captured hipGraph, inputs (prompt embeddings, per-request noise)
+already resident in HBM.  Workload at N=1 = BASELINE.json configs[1]: SD1.5 512x512, 4 steps, batch 1, fp16,
+hipGraph.  Independent requests shard across ranks with no data-path collective (weak scaling, fixed
+per-GPU batch); the only exchange is one RCCL broadcast of the prompt embeddings before the timed region.
+Weights are seeded synthetic SD1.5-architecture weights (no checkpoint ships with the reference).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_F16_PEAK_TFLOPS = 2500.0   # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(threads):
+    """Oracle (CPU restatement, kind 'port') on a bounded sample of the same workload:
+    one UNet forward + one VAE decode at 512x512 (latent 64x64); image time = 4*unet + vae."""
+    import numpy as np
+    import torch
+    from sdlcm_amd import weights
+    from oracle.unet import UNetOracle
+    from oracle.vae import VAEDecoderOracle
+    from oracle import glue
+    torch.set_num_threads(threads)
+    unet = UNetOracle(weights.synthetic_unet())
+    vae = VAEDecoderOracle(weights.synthetic_vae())
+    g = torch.Generator().manual_seed(0)
+    lat = torch.randn(1, 4, 64, 64, generator=g)
+    pe = torch.randn(1, 77, 768, generator=g)
+    cond = torch.from_numpy(glue.guidance_scale_embedding(np.zeros(1, np.float32), 256))
+    t0 = time.time(); unet.forward(lat, 999, pe, cond); t_unet = time.time() - t0
+    t0 = time.time(); vae.decode(lat); t_vae = time.time() - t0
+    t_img = 4 * t_unet + t_vae
+    return {"value": 1.0 / t_img, "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"1 UNet forward ({t_unet:.2f}s) + 1 VAE decode ({t_vae:.2f}s) at 512x512 on torch-CPU fp32; "
+                      f"image = 4*unet + vae = {t_img:.1f}s"}
+
+
+def roofline_leg(pipe, P, guidance):
+    """Live per-launch HIP-event timing of the dominant kernel (implicit-GEMM conv3x3 on MFMA) over one eager
+    pass of the same workload; achieved = algorithmic FLOP of those launches / their summed duration."""
+    import torch
+    from sdlcm_amd import ops
+    ops.PROFILE = []
+    with torch.cuda.stream(pipe.stream):
+        pipe._enqueue(P, guidance)
+        pipe.stream.synchronize()
+    recs, ops.PROFILE = ops.PROFILE, None
+    agg = {}
+    for r in recs:
+        k = (r["kind"], r["tile"])
+        a = agg.setdefault(k, dict(n=0, flops=0.0, ms=0.0))
+        a["n"] += 1; a["flops"] += r["flops"]; a["ms"] += r["e0"].elapsed_time(r["e1"])
+    (kind, tile), dom = max(agg.items(), key=lambda kv: kv[1]["ms"])
+    ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+    table = {f"{k[0]}[{k[1]}]": {"launches": v["n"], "ms": round(v["ms"], 3),
+                                 "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)} for k, v in agg.items()}
+    tot_f = sum(v["flops"] for v in agg.values()); tot_ms = sum(v["ms"] for v in agg.values())
+    return {"bound": "mfma", "kernel": f"igemm_kernel<{tile.replace('x', ',')},{1 if kind == 'conv3x3' else 0}> ({kind})",
+            "achieved": round(ach, 1), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_F16_PEAK_TFLOPS, 4),
+            "launches": dom["n"], "avg_launch_us": round(dom["ms"] * 1e3 / dom["n"], 1), "traffic": None,
+            "all_mfma_kernels": {"tflops": round(tot_f / (tot_ms * 1e-3) / 1e12, 1), "ms": round(tot_ms, 3)},
+            "by_kernel": table}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1, help="images per GPU per step (BASELINE configs[1]: 1)")
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--lcm-steps", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import sdlcm_amd  # noqa: F401
+    from sdlcm_amd import weights
+    from sdlcm_amd.pipeline import LcmHipPipeline, draw_noise, guidance_scale_embedding
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
+    dev = f"cuda:{local}"
+    pipe = LcmHipPipeline(weights.synthetic_unet(), weights.synthetic_vae(), device=dev)
+    B, S, n = args.batch, args.size, args.lcm_steps
+    h = w = S // 8
+
+    def prime(Bx):
+        """Fill a plan's resident inputs: embeddings broadcast from rank 0 over RCCL, per-request noise."""
+        P = pipe.plan(Bx, h, w, n)
+        with torch.cuda.stream(pipe.stream):
+            allpe = torch.empty(world * Bx, 77, 768, dtype=torch.float16, device=dev)
+            if rank == 0:
+                allpe.copy_(torch.randn(world * Bx, 77, 768, generator=torch.Generator().manual_seed(1)).half())
+            if dist is not None:
+                pipe.stream.synchronize()
+                dist.broadcast(allpe, src=0)          # the one exchange step: 118 KB per prompt over xGMI
+                torch.cuda.synchronize()
+            P.ehs.copy_(allpe[rank * Bx:(rank + 1) * Bx].reshape(Bx * 77, 768))
+            for b in range(Bx):
+                l0, extra = draw_noise(1000 + rank * Bx + b, h, w, n - 1)
+                P.lat0[b].copy_(l0[0])
+                for i, e in enumerate(extra):
+                    P.noise[i, b].copy_(e[0])
+            P.wemb.copy_(torch.from_numpy(guidance_scale_embedding(np.zeros(Bx, np.float32), P.wemb.shape[1])).half())
+            pipe._enqueue(P, 1.0)                      # eager warm-up: allocates scratch
+            pipe.stream.synchronize()
+            from sdlcm_amd import ops
+            g = ops.Graph()
+            with g:
+                pipe._enqueue(P, 1.0)
+            P.graph = g
+        return P
+
+    def timed(P, K, W):
+        with torch.cuda.stream(pipe.stream):
+            for _ in range(W):
+                P.graph.launch()
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(K + 1)]
+            t0 = time.perf_counter()
+            evs[0].record()
+            for i in range(K):
+                P.graph.launch()
+                evs[i + 1].record()
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        lat = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(K))
+        return dt, lat[len(lat) // 2]
+
+    P = prime(B)
+    dt, p50 = timed(P, args.steps, args.warmup)
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    images = world * B * args.steps
+    line = {
+        "metric": "512x512 4-step LCM images/sec", "value": round(images / dt, 3), "unit": "images/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+        "p50_latency_ms": round(p50, 3),
+        "config": {"workload": f"SD1.5 LCM {S}x{S}, {n} steps, guidance 1.0, batch {B} per GPU, fp16 (fp32 accumulate), "
+                               "hipGraph replay; seeded synthetic SD1.5-architecture weights",
+                   "batch_per_gpu": B, "global_batch": world * B, "image": f"{S}x{S}", "lcm_steps": n,
+                   "parallelism": f"independent requests x{world} (RCCL broadcast of prompt embeddings only)"},
+    }
+    if rank == 0 and world == 1:
+        line["roofline"] = roofline_leg(pipe, P, 1.0)
+        fl_img = 5.74e12 * (S * S) / (512 * 512) * n / 4
+        line["pipeline_tflops"] = round(fl_img * B / (dt / args.steps) / 1e12, 1)
+        if not args.no_extra and B == 1:
+            P8 = prime(8)
+            dt8, p508 = timed(P8, max(3, args.steps // 4), 1)
+            k8 = max(3, args.steps // 4)
+            line["extra_batch8"] = {"images_per_s": round(8 * k8 / dt8, 2), "ms_per_step": round(dt8 / k8 * 1e3, 2),
+                                    "pipeline_tflops": round(fl_img * 8 / (dt8 / k8) / 1e12, 1),
+                                    "workload": "same, batch 8 per GPU (BASELINE configs[2] per-GPU shard)"}
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

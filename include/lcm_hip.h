@@ -47,6 +47,9 @@ int lcm_gemm_f16(const void* A, int lda, const void* A2, int lda2, int K1,
                  int M, int N, int K, int epilogue, float out_scale,
                  int batch, int64_t strideA, int64_t strideW, int64_t strideO, void* stream);
 
+/* tile shape the contraction kernels use for an [M x N] output (BM*1000 + BN); for profiling / docs */
+int lcm_gemm_tile_config(int M, int N, int batch);
+
 /* ---- 3x3 convolution, padding 1 (ResnetBlock2D.conv1/conv2, Downsample2D, Upsample2D.conv) ----
  * implicit GEMM over K = 9*Cin on MFMA; in: [B,Hin,Win,Cin]; stride 1|2; ups=1 reads the input through a
  * nearest-2x upsample (F.interpolate(scale_factor=2) fused into the loader).  Epilogue as lcm_gemm_f16.

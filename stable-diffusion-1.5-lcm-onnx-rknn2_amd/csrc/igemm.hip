@@ -233,15 +233,26 @@ static int launch_cfg(IgemmParams& p, int batch, hipStream_t s) {
     return LCM_OK;
 }
 
+// tile selection: the largest tile that still gives >= 2 workgroups per CU; else the most tiles
+static int pick_tile(int M, int N, int batch) {
+    const bool n128 = (N % 128) == 0;
+    auto tiles = [&](int bm, int bn) { return (long long)((M + bm - 1) / bm) * (N / bn) * batch; };
+    if (n128 && M >= 128 && tiles(128, 128) >= 512) return 128 * 1000 + 128;
+    if (M >= 128 && tiles(128, 64) >= 512) return 128 * 1000 + 64;
+    if (n128 && M > 64 && M < 128) return 64 * 1000 + 128;
+    return 64 * 1000 + 64;
+}
+
+extern "C" int lcm_gemm_tile_config(int M, int N, int batch) { return pick_tile(M, N, batch); }
+
 template <int MODE>
 static int launch_igemm(IgemmParams& p, int batch, hipStream_t s) {
-    const bool n128 = (p.N % 128) == 0;
-    auto tiles = [&](int bm, int bn) { return (long long)((p.M + bm - 1) / bm) * (p.N / bn) * batch; };
-    // prefer the largest tile that still gives >= 2 workgroups per CU; fall back to the most tiles
-    if (n128 && p.M >= 128 && tiles(128, 128) >= 512) return launch_cfg<128, 128, MODE>(p, batch, s);
-    if (p.M >= 128 && tiles(128, 64) >= 512) return launch_cfg<128, 64, MODE>(p, batch, s);
-    if (n128 && p.M > 64 && p.M < 128) return launch_cfg<64, 128, MODE>(p, batch, s);
-    return launch_cfg<64, 64, MODE>(p, batch, s);
+    switch (pick_tile(p.M, p.N, batch)) {
+        case 128128: return launch_cfg<128, 128, MODE>(p, batch, s);
+        case 128064: return launch_cfg<128, 64, MODE>(p, batch, s);
+        case 64128: return launch_cfg<64, 128, MODE>(p, batch, s);
+        default: return launch_cfg<64, 64, MODE>(p, batch, s);
+    }
 }
 
 extern "C" int lcm_gemm_f16(const void* A, int lda, const void* A2, int lda2, int K1,

@@ -18,6 +18,35 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# Optional live per-launch timing (bench.py's roofline leg): when PROFILE is a list, every contraction /
+# attention launch is bracketed by HIP events recorded on the stream the kernel runs on.
+PROFILE = None
+
+
+class _Timed:
+    def __init__(self, kind, tile, flops, bytes_):
+        self.rec = None
+        if PROFILE is not None:
+            self.rec = dict(kind=kind, tile=tile, flops=float(flops), bytes=float(bytes_),
+                            e0=torch.cuda.Event(enable_timing=True), e1=torch.cuda.Event(enable_timing=True))
+
+    def __enter__(self):
+        if self.rec is not None:
+            self.rec["e0"].record()
+        return self
+
+    def __exit__(self, *a):
+        if self.rec is not None:
+            self.rec["e1"].record()
+            PROFILE.append(self.rec)
+        return False
+
+
+def tile_config(M, N, batch=1):
+    c = _lib.load().lcm_gemm_tile_config(int(M), int(N), int(batch))
+    return f"{c // 1000}x{c % 1000}"
+
+
 def gemm(a, w, out, *, bias=None, res=None, rowadd=None, rows_per_batch=0, a2=None, epilogue=0, out_scale=1.0,
          M=None, N=None, K=None, lda=None, ldo=None, batch=1, strideA=0, strideW=0, strideO=0):
     """out[m][n] = out_scale * sum_k [a|a2][m][k] w[n][k] + bias + rowadd + res  (see include/lcm_hip.h)."""
@@ -28,18 +57,24 @@ def gemm(a, w, out, *, bias=None, res=None, rowadd=None, rows_per_batch=0, a2=No
     N = w.shape[0] if N is None else N
     lda = a.stride(-2) if lda is None else lda
     ldo = out.stride(-2) if ldo is None else ldo
-    rc = L.lcm_gemm_f16(_p(a), lda, _p(a2), a2.stride(0) if a2 is not None else 0, K1, _p(w), _p(bias), _p(rowadd),
-                        rowadd.stride(0) if rowadd is not None else 0, rows_per_batch,
-                        _p(res), res.stride(0) if res is not None else 0, _p(out), ldo,
-                        M, N, K, epilogue, float(out_scale), batch, strideA, strideW, strideO, _stream())
+    with _Timed("gemm", tile_config(M, N, batch) if PROFILE is not None else "", 2.0 * M * N * K * batch,
+                2.0 * batch * (M * K + N * K + M * N)):
+        rc = L.lcm_gemm_f16(_p(a), lda, _p(a2), a2.stride(0) if a2 is not None else 0, K1, _p(w), _p(bias), _p(rowadd),
+                            rowadd.stride(0) if rowadd is not None else 0, rows_per_batch,
+                            _p(res), res.stride(0) if res is not None else 0, _p(out), ldo,
+                            M, N, K, epilogue, float(out_scale), batch, strideA, strideW, strideO, _stream())
     _lib.check(rc, "lcm_gemm_f16")
     return out
 
 
 def conv3x3(x, w, out, B, H, W, Cin, Cout, *, bias=None, rowadd=None, res=None, stride=1, ups=0):
     L = _lib.load()
-    rc = L.lcm_conv3x3_f16(_p(x), _p(w), _p(bias), _p(rowadd), rowadd.stride(0) if rowadd is not None else 0,
-                           _p(res), _p(out), B, H, W, Cin, Cout, stride, ups, _stream())
+    Ho, Wo = ((2 * H, 2 * W) if ups else ((H + 1) // 2, (W + 1) // 2) if stride == 2 else (H, W))
+    Mo = B * Ho * Wo
+    with _Timed("conv3x3", tile_config(Mo, Cout) if PROFILE is not None else "", 2.0 * Mo * Cout * 9 * Cin,
+                2.0 * (B * H * W * Cin + 9 * Cin * Cout + Mo * Cout)):
+        rc = L.lcm_conv3x3_f16(_p(x), _p(w), _p(bias), _p(rowadd), rowadd.stride(0) if rowadd is not None else 0,
+                               _p(res), _p(out), B, H, W, Cin, Cout, stride, ups, _stream())
     _lib.check(rc, "lcm_conv3x3_f16")
     return out
 
@@ -80,7 +115,8 @@ def layernorm(x, gamma, beta, out, M, C, eps=1e-5):
 def attention(q, k, v, out, B, heads, Sq, Sk, d, *, ldq, ldk, ldv, ldo, scale=None):
     L = _lib.load()
     scale = d ** -0.5 if scale is None else scale
-    rc = L.lcm_attention_f16(_p(q), ldq, _p(k), ldk, _p(v), ldv, _p(out), ldo, B, heads, Sq, Sk, d, float(scale), _stream())
+    with _Timed("attention", f"d{d}", 4.0 * B * heads * Sq * Sk * d, 2.0 * B * heads * d * (2 * Sq + 2 * Sk)):
+        rc = L.lcm_attention_f16(_p(q), ldq, _p(k), ldk, _p(v), ldv, _p(out), ldo, B, heads, Sq, Sk, d, float(scale), _stream())
     _lib.check(rc, "lcm_attention_f16")
     return out
 
