@@ -23,6 +23,15 @@ MFMA_F16_PEAK_TFLOPS = 2500.0   # MI355X dense fp16/bf16 MFMA peak (MI355X_MICRO
 HBM_PEAK_GBS = 8000.0
 
 
+def host_threads():
+    """Host cores this process may use (a 1-GPU box shares 16 of the host's cores per GPU)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    return max(1, min(n, int(os.environ.get("LCM_CPU_THREADS", "16"))))
+
+
 def cpu_baseline(threads):
     """Oracle (CPU restatement, kind 'port') on a bounded sample of the same workload:
     one UNet forward + one VAE decode at 512x512 (latent 64x64); image time = 4*unet + vae."""
@@ -54,6 +63,8 @@ def roofline_leg(pipe, P, guidance):
     from sdlcm_amd import ops
     ops.PROFILE = []
     with torch.cuda.stream(pipe.stream):
+        # hold the stream while the host enqueues, so the events bracket back-to-back GPU execution
+        ops.debug_spin(min(2000000, 150000 + 120000 * P.B))
         pipe._enqueue(P, guidance)
         pipe.stream.synchronize()
     recs, ops.PROFILE = ops.PROFILE, None
@@ -184,7 +195,7 @@ def main():
                                     "pipeline_tflops": round(fl_img * 8 / (dt8 / k8) / 1e12, 1),
                                     "workload": "same, batch 8 per GPU (BASELINE configs[2] per-GPU shard)"}
         if not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
+            line["cpu_baseline"] = cpu_baseline(host_threads())
     if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:

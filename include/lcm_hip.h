@@ -120,6 +120,9 @@ int lcm_scheduler_step(const void* eps, const void* eps_uncond, float guidance, 
 /* ---- adaptive_avg_pool2d(lat,(8,8)) -> fp16 [B,4,8,8] (run_job_with_latents, backends/cuda_worker.py:299-304) */
 int lcm_latents_pool8(const void* lat, void* out_f16, int B, int h, int w, void* stream);
 
+/* profiling aid: hold the stream busy for `usec` (<= 2 s) so queued launches run back to back */
+int lcm_debug_spin(int usec, void* stream);
+
 /* ---- hipGraph capture of the 4-step sampler loop + VAE ---- */
 int lcm_graph_begin(void* stream);
 int lcm_graph_end(void* stream, void** graph_exec_out);

@@ -314,3 +314,27 @@ extern "C" int lcm_transpose_f16(const void* in, int ldi, void* out, int ldo, in
     LCM_CHECK_LAUNCH("transpose");
     return LCM_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Profiling aid: occupy the stream for `usec` microseconds (one wave polling the 100 MHz realtime counter,
+// bounded by construction) so that a host-bound eager enqueue queues up behind it and per-launch HIP events
+// then time back-to-back GPU execution rather than host launch latency.  Not on the product path.
+// ---------------------------------------------------------------------------------------------
+__global__ void spin_kernel(unsigned long long ticks, unsigned long long* sink) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long t = t0;
+    // hard bound on iterations as well as on time: every wave exits
+    for (long long i = 0; i < (1ll << 34) && (t - t0) < ticks; ++i) {
+        __builtin_amdgcn_s_sleep(64);
+        t = __builtin_amdgcn_s_memrealtime();
+    }
+    if (sink && threadIdx.x == 0) *sink = t - t0;
+}
+
+extern "C" int lcm_debug_spin(int usec, void* stream) {
+    LCM_REQUIRE(usec >= 0 && usec <= 2000000, "debug_spin: usec out of range");
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long)usec * 100ull,
+                       (unsigned long long*)nullptr);
+    LCM_CHECK_LAUNCH("debug_spin");
+    return LCM_OK;
+}

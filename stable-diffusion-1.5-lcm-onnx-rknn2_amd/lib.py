@@ -50,6 +50,7 @@ _SIGS = {
     "lcm_graph_launch": [_vp, _vp],
     "lcm_graph_destroy": [_vp],
     "lcm_gemm_tile_config": [_i, _i, _i],
+    "lcm_debug_spin": [_i, _vp],
     "lcm_device_info": [_i, C.c_char_p, _i, C.POINTER(_i), C.POINTER(C.c_uint64)],
 }
 EXPORTS = tuple(sorted(list(_SIGS) + ["lcm_last_error", "lcm_version", "lcm_groupnorm_ws_bytes"]))

@@ -163,6 +163,10 @@ def latents_pool8(lat, out, B, h, w):
     return out
 
 
+def debug_spin(usec):
+    _lib.check(_lib.load().lcm_debug_spin(int(usec), _stream()), "lcm_debug_spin")
+
+
 class Graph:
     """hipGraph captured from the kernels enqueued on the current torch stream."""
 

@@ -1,0 +1,141 @@
+"""CPU-side tests of the product: host glue against the golden vectors and the oracle, weight inventory,
+packing, the C ABI surface (library loads and exports every symbol include/lcm_hip.h declares), and the
+loud failure of the product path without a GPU."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "glue_golden.npz"))
+
+
+def test_abi_exports_every_declared_symbol():
+    import __graft_entry__
+    __graft_entry__.build()
+    from sdlcm_amd import lib
+    L = lib.load()
+    hdr = open(os.path.join(ROOT, "include", "lcm_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(lcm_[a-z0-9_]+)\s*\(", hdr)))
+    assert declared, "no declarations parsed"
+    for name in declared:
+        assert hasattr(L, name), f"liblcmhip.so does not export {name}"
+    assert sorted(lib.EXPORTS) == declared
+    assert L.lcm_version() >= 100
+
+
+def test_abi_argument_validation_without_gpu():
+    """Precondition checks run before any launch, so they are testable on the CPU box."""
+    import ctypes as C
+    from sdlcm_amd import lib
+    L = lib.load()
+    rc = L.lcm_gemm_f16(None, 0, None, 0, 0, None, None, None, 0, 0, None, 0, None, 0, 1, 64, 64, 0, 1.0, 1, 0, 0, 0, None)
+    assert rc == -1 and b"null pointer" in L.lcm_last_error()
+    buf = C.create_string_buffer(16)
+    p = C.cast(buf, C.c_void_p)
+    rc = L.lcm_gemm_f16(p, 8, None, 0, 0, p, None, None, 0, 0, None, 0, p, 8, 4, 64, 100, 0, 1.0, 1, 0, 0, 0, None)
+    assert rc == -1 and b"multiple of 64" in L.lcm_last_error()
+    rc = L.lcm_attention_f16(p, 8, p, 8, p, 8, p, 8, 1, 8, 4, 4, 48, 1.0, None)
+    assert rc == -1 and b"head_dim" in L.lcm_last_error()
+    with pytest.raises(lib.LcmHipError):
+        lib.check(rc, "attention")
+    assert L.lcm_gemm_tile_config(262144, 128, 1) == 128128
+
+
+def test_product_glue_matches_reference_vectors():
+    from sdlcm_amd.pipeline import draw_noise, guidance_scale_embedding
+    assert np.allclose(guidance_scale_embedding(G["gse_w"], 256), G["gse_256"], atol=1e-6)
+    assert np.allclose(guidance_scale_embedding(G["gse_w"], 255), G["gse_255"], atol=1e-6)
+    lat, extra = draw_noise(42, 64, 64, 1)
+    assert np.array_equal(lat.numpy(), G["latents_seed42_512x512"])
+    assert np.array_equal(extra[0].numpy(), G["noise1_seed42_512x512"])
+
+
+def test_schedule_matches_oracle_and_config_override(tmp_path):
+    from oracle.scheduler import LCMSchedulerOracle
+    from sdlcm_amd.scheduler import LCMSchedule
+    s, o = LCMSchedule(), LCMSchedulerOracle()
+    for n in (1, 2, 4, 8, 50):
+        ts = s.timesteps(n)
+        assert list(ts) == list(o.set_timesteps(n))
+        for i in range(n):
+            c, last = s.step_coefficients(ts, i)
+            oc = o.coefficients(i)
+            assert np.allclose(c, oc[:6], rtol=1e-7) and last == oc[6]
+    with pytest.raises(ValueError):
+        s.timesteps(51)
+    p = tmp_path / "scheduler_config.json"
+    p.write_text('{"beta_start": 0.001, "beta_end": 0.02, "original_inference_steps": 100, "_class_name": "X"}')
+    s2 = LCMSchedule.from_config_file(str(p))
+    assert s2.original_inference_steps == 100 and list(s2.timesteps(2)) == [999, 499]
+    assert LCMSchedule.from_config_file(str(tmp_path / "missing.json")).original_inference_steps == 50
+
+
+def test_weight_inventory_matches_known_parameter_counts():
+    from sdlcm_amd import weights
+    assert weights.count_params(weights.unet_param_spec()) == 859_602_884      # 859.52 M + cond_proj 81,920
+    assert weights.count_params(weights.unet_param_spec(dict(time_cond_proj_dim=None))) == 859_520_964
+    assert weights.count_params(weights.vae_param_spec()) == 49_490_199
+    names = [n for n, _, _ in weights.unet_param_spec()]
+    assert len(names) == len(set(names)) and "up_blocks.3.attentions.2.proj_out.weight" in names
+
+
+def test_packing_layouts():
+    from sdlcm_amd.packing import pack_conv3x3, pack_geglu
+    w = torch.arange(2 * 3 * 9, dtype=torch.float32).reshape(2, 3, 3, 3)
+    p = pack_conv3x3(w)
+    assert p.shape == (2, 27)
+    for tap in range(9):
+        assert torch.equal(p[1, tap * 3:(tap + 1) * 3], w[1, :, tap // 3, tap % 3])
+    wg = torch.arange(64 * 2, dtype=torch.float32).reshape(64, 2)
+    bg = torch.arange(64, dtype=torch.float32)
+    wp, bp = pack_geglu(wg, bg)
+    # packed row 32q+r (r<16) = value row 16q+r ; 32q+16+r = gate row 32+16q+r
+    for q in range(2):
+        assert torch.equal(wp[32 * q:32 * q + 16], wg[16 * q:16 * q + 16])
+        assert torch.equal(wp[32 * q + 16:32 * q + 32], wg[32 + 16 * q:32 + 16 * q + 16])
+        assert torch.equal(bp[32 * q + 16:32 * q + 32], bg[32 + 16 * q:32 + 16 * q + 16])
+
+
+def test_worker_interface_mirror_and_errors(monkeypatch):
+    from sdlcm_amd.backends import base, hip_worker, worker_factory
+    from sdlcm_amd.lib import LcmHipError
+    assert set(base.PipelineWorker.__annotations__) == {"worker_id"}
+    assert hasattr(base.PipelineWorker, "run_job") and hasattr(base.PipelineWorker, "run_job_with_latents")
+    assert hip_worker.parse_size("512X768") == (512, 768)
+    with pytest.raises(RuntimeError, match="Invalid size 'bad', expected 'WIDTHxHEIGHT'"):
+        hip_worker.parse_size("bad")
+    monkeypatch.delenv("MODEL_ROOT", raising=False)
+    monkeypatch.delenv("MODEL", raising=False)
+    with pytest.raises(RuntimeError, match="MODEL_ROOT"):
+        worker_factory.create_hip_worker(worker_id=0)
+    monkeypatch.setenv("MODEL_ROOT", "/nonexistent")
+    with pytest.raises(RuntimeError, match="MODEL "):
+        worker_factory.create_hip_worker(worker_id=0)
+    monkeypatch.setenv("MODEL", "nope")
+    with pytest.raises(RuntimeError, match="not found"):
+        worker_factory.create_hip_worker(worker_id=0)
+    if not torch.cuda.is_available():
+        monkeypatch.setenv("MODEL", "synthetic")
+        with pytest.raises(LcmHipError, match="no CPU fallback"):       # product path fails loudly, never falls back
+            worker_factory.create_hip_worker(worker_id=0)
+
+
+def test_png_encoding_is_deterministic_and_lossless():
+    import io
+    from PIL import Image
+    from sdlcm_amd.backends.hip_worker import encode_png
+    rgb = np.random.RandomState(0).randint(0, 256, size=(64, 48, 3), dtype=np.uint8)
+    a, b = encode_png(rgb), encode_png(rgb)
+    assert a == b and a[:8] == b"\x89PNG\r\n\x1a\n"
+    assert np.array_equal(np.asarray(Image.open(io.BytesIO(a))), rgb)
+
+
+def test_synthetic_prompt_encoder_is_deterministic():
+    from sdlcm_amd.prompt import SyntheticPromptEncoder
+    e = SyntheticPromptEncoder()
+    a, b, c = e(["a cat"]), e(["a cat"]), e(["a dog"])
+    assert a.shape == (1, 77, 768) and a.dtype == torch.float16
+    assert torch.equal(a, b) and not torch.equal(a, c)
