@@ -47,6 +47,18 @@ int lcm_gemm_f16(const void* A, int lda, const void* A2, int lda2, int K1,
                  int M, int N, int K, int epilogue, float out_scale,
                  int batch, int64_t strideA, int64_t strideW, int64_t strideO, void* stream);
 
+/* Optional fp32 scratch for deterministic split-K (deep-K, small-M layers).  The caller owns the memory; it is
+ * registered per current device and must outlive every later launch (graph replays included).  Without it the
+ * contraction kernels never split.  bytes >= 4*splits*M*N of the layers that should split (32 MiB covers SD1.5). */
+int lcm_set_workspace(void* ptr, int64_t bytes);
+
+/* launch heuristics of the contraction kernels (0 keeps a value): workgroups a split-K launch aims for, the
+ * maximum number of K splits, and the workgroup count below which a larger tile is passed over. */
+int lcm_set_tuning(int target_wgs, int max_splits, int min_wgs);
+
+/* contraction kernel variant: 0 = register-staged double buffer, 2/3/4 = LDS-DMA pipeline with that many stages */
+int lcm_set_kernel_variant(int variant);
+
 /* tile shape the contraction kernels use for an [M x N] output (BM*1000 + BN); for profiling / docs */
 int lcm_gemm_tile_config(int M, int N, int batch);
 

@@ -34,12 +34,76 @@ struct IgemmParams {
     // conv
     int Hin, Win, Cin, Hout, Wout, stride, ups;
     int mtiles, ntiles;
+    int splits;          // split-K: blockIdx.y owns k-tiles [y*nk/splits, (y+1)*nk/splits); partials -> ws
+    float* ws;           // fp32 [splits][M][N]
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     // contiguous chunk of tiles per XCD (blocks are dealt round-robin over the 8 XCDs)
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+template <int BM, int BN>
+__device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f4 (&acc)[BN / 32][BM / 32], int m_base, int n_base,
+                                               int wm, int wn, int frow, int fq, int z) {
+    constexpr int TM = BM / 32, TN = BN / 32;
+    if (p.splits > 1) {   // split-K: raw fp32 partial slab, epilogue runs in splitk_reduce_kernel
+        float* __restrict__ wsb = p.ws + (long long)blockIdx.y * p.M * p.N;
+#pragma unroll
+        for (int b = 0; b < TM; ++b) {
+            const int m = m_base + wm * (BM / 2) + b * 16 + frow;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int a = 0; a < TN; ++a) {
+                const int n = n_base + wn * (BN / 2) + a * 16 + fq * 4;
+                *reinterpret_cast<f4*>(wsb + (long long)m * p.N + n) = acc[a][b];
+            }
+        }
+        return;
+    }
+
+    // ---- epilogue: lane holds out[m = ..+frow][n = ..+fq*4 .. +3] ----
+    half_t* __restrict__ outb = p.out + z * p.strideO;
+#pragma unroll
+    for (int b = 0; b < TM; ++b) {
+        const int m = m_base + wm * (BM / 2) + b * 16 + frow;
+        if (m >= p.M) continue;
+        const half_t* radd = p.rowadd ? p.rowadd + (long long)(m / p.rows_per_batch) * p.ld_rowadd : nullptr;
+        if (p.epi == 0) {
+#pragma unroll
+            for (int a = 0; a < TN; ++a) {
+                const int n = n_base + wn * (BN / 2) + a * 16 + fq * 4;
+                f4 v = acc[a][b];
+                if (p.bias) { h4 t = *reinterpret_cast<const h4*>(p.bias + n);
+                    v[0] += (float)t[0]; v[1] += (float)t[1]; v[2] += (float)t[2]; v[3] += (float)t[3]; }
+                if (radd) { h4 t = *reinterpret_cast<const h4*>(radd + n);
+                    v[0] += (float)t[0]; v[1] += (float)t[1]; v[2] += (float)t[2]; v[3] += (float)t[3]; }
+                v[0] *= p.out_scale; v[1] *= p.out_scale; v[2] *= p.out_scale; v[3] *= p.out_scale;
+                if (p.res) { h4 t = *reinterpret_cast<const h4*>(p.res + (long long)m * p.ldr + n);
+                    v[0] += (float)t[0]; v[1] += (float)t[1]; v[2] += (float)t[2]; v[3] += (float)t[3]; }
+                h4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                *reinterpret_cast<h4*>(outb + (long long)m * p.ldo + n) = o;
+            }
+        } else {  // GEGLU: even n-tile = value rows, odd n-tile = gate rows (16-row interleave)
+#pragma unroll
+            for (int a = 0; a < TN; a += 2) {
+                const int n = n_base + wn * (BN / 2) + a * 16 + fq * 4;      // packed row of the value
+                f4 x = acc[a][b], g = acc[a + 1][b];
+                if (p.bias) {
+                    h4 tx = *reinterpret_cast<const h4*>(p.bias + n);
+                    h4 tg = *reinterpret_cast<const h4*>(p.bias + n + 16);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { x[j] += (float)tx[j]; g[j] += (float)tg[j]; }
+                }
+                h4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (half_t)(x[j] * gelu_erf_f(g[j]));
+                const int nout = ((n_base + wn * (BN / 2) + a * 16) >> 1) + fq * 4;
+                *reinterpret_cast<h4*>(outb + (long long)m * p.ldo + nout) = o;
+            }
+        }
+    }
 }
 
 template <int BM, int BN, int MODE>
@@ -83,7 +147,9 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
     const half_t* wptr = Wb + (long long)(n_base + row0) * p.K + chunk * 8;
 
     h8 ra[RA], rw[RW];
-    const int nk = p.K >> 6;
+    const int nk_all = p.K >> 6;
+    const int kt0 = (int)((long long)blockIdx.y * nk_all / p.splits);
+    const int kt1 = (int)((long long)(blockIdx.y + 1) * nk_all / p.splits);
 
     auto load_tile = [&](int kt) {
         if (MODE == 0) {
@@ -137,13 +203,13 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
 
     const int frow = lane & 15, fq = lane >> 4;
 
-    load_tile(0);
+    load_tile(kt0);
     store_tile(0);
     __syncthreads();
 
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int cur = (kt - kt0) & 1;
+        if (kt + 1 < kt1) load_tile(kt + 1);
         const char* xs = smem + cur * BUF + (wm * (BM / 2)) * 128;
         const char* ws = smem + cur * BUF + XBYTES + (wn * (BN / 2)) * 128;
 #pragma unroll
@@ -166,92 +232,307 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
                 for (int b = 0; b < TM; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[a], xf[b], acc[a][b], 0, 0, 0);
         }
-        if (kt + 1 < nk) store_tile(cur ^ 1);
+        if (kt + 1 < kt1) store_tile(cur ^ 1);
         __syncthreads();
     }
 
-    // ---- epilogue: lane holds out[m = ..+frow][n = ..+fq*4 .. +3] ----
-    half_t* __restrict__ outb = p.out + z * p.strideO;
+    igemm_epilogue<BM, BN>(p, acc, m_base, n_base, wm, wn, frow, fq, z);
+}
+
+// ------------------------------------------------------------------------------------------------
+// v2: the same tile / MFMA / epilogue structure fed by LDS-DMA (global_load_lds_dwordx4): no staging VGPRs, no
+// ds_write pass, S LDS stages with a COUNTED s_waitcnt vmcnt so S-2 tiles stay in flight across the single raw
+// s_barrier per K-step.  The DMA destination is lane-linear (wave base + lane*16), so the XOR swizzle is applied
+// to the per-lane SOURCE chunk (lane at position pos of row r fetches chunk pos ^ (r&7)); the swizzled
+// ds_read_b128 addresses are unchanged.  Zero fill (image border, m >= M) = source pointer into a zero page.
+// ------------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(256))) half_t g_zero_page[128];
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int BM, int BN, int MODE, int S>
+__global__ __launch_bounds__(256, 2) void igemm2_kernel(IgemmParams p) {
+    constexpr int RA = BM / 32, RW = BN / 32;
+    constexpr int TM = BM / 32, TN = BN / 32;
+    constexpr int XBYTES = BM * 128, WBYTES = BN * 128, BUF = XBYTES + WBYTES;
+    constexpr int LPT = RA + RW;                 // LDS-DMA instructions per thread per tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, wn = wave >> 1;
+    const int tile = xcd_remap(blockIdx.x, p.mtiles * p.ntiles);
+    const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
+    const int m_base = mt * BM, n_base = nt * BN;
+    const int z = blockIdx.z;
+
+    const half_t* __restrict__ Ab = p.A + z * p.strideA;
+    const half_t* __restrict__ A2b = p.A2 ? p.A2 + z * p.strideA : nullptr;
+    const half_t* __restrict__ Wb = p.W + z * p.strideW;
+
+    const int pos = tid & 7, row0 = tid >> 3;
+    const int schunk = (pos ^ (row0 & 7)) * 8;      // source chunk (halves) this lane fetches
+
+    bool a_ok[RA];
+    long long a_off[RA];
+    int a_b[RA], a_y[RA], a_x[RA];
 #pragma unroll
-    for (int b = 0; b < TM; ++b) {
-        const int m = m_base + wm * (BM / 2) + b * 16 + frow;
-        if (m >= p.M) continue;
-        const half_t* radd = p.rowadd ? p.rowadd + (long long)(m / p.rows_per_batch) * p.ld_rowadd : nullptr;
-        if (p.epi == 0) {
-#pragma unroll
-            for (int a = 0; a < TN; ++a) {
-                const int n = n_base + wn * (BN / 2) + a * 16 + fq * 4;
-                f4 v = acc[a][b];
-                if (p.bias) { h4 t = *reinterpret_cast<const h4*>(p.bias + n);
-                    v[0] += (float)t[0]; v[1] += (float)t[1]; v[2] += (float)t[2]; v[3] += (float)t[3]; }
-                if (radd) { h4 t = *reinterpret_cast<const h4*>(radd + n);
-                    v[0] += (float)t[0]; v[1] += (float)t[1]; v[2] += (float)t[2]; v[3] += (float)t[3]; }
-                v[0] *= p.out_scale; v[1] *= p.out_scale; v[2] *= p.out_scale; v[3] *= p.out_scale;
-                if (p.res) { h4 t = *reinterpret_cast<const h4*>(p.res + (long long)m * p.ldr + n);
-                    v[0] += (float)t[0]; v[1] += (float)t[1]; v[2] += (float)t[2]; v[3] += (float)t[3]; }
-                h4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-                *reinterpret_cast<h4*>(outb + (long long)m * p.ldo + n) = o;
-            }
-        } else {  // GEGLU: even n-tile = value rows, odd n-tile = gate rows (16-row interleave)
-#pragma unroll
-            for (int a = 0; a < TN; a += 2) {
-                const int n = n_base + wn * (BN / 2) + a * 16 + fq * 4;      // packed row of the value
-                f4 x = acc[a][b], g = acc[a + 1][b];
-                if (p.bias) {
-                    h4 tx = *reinterpret_cast<const h4*>(p.bias + n);
-                    h4 tg = *reinterpret_cast<const h4*>(p.bias + n + 16);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) { x[j] += (float)tx[j]; g[j] += (float)tg[j]; }
-                }
-                h4 o;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = (half_t)(x[j] * gelu_erf_f(g[j]));
-                const int nout = ((n_base + wn * (BN / 2) + a * 16) >> 1) + fq * 4;
-                *reinterpret_cast<h4*>(outb + (long long)m * p.ldo + nout) = o;
-            }
+    for (int i = 0; i < RA; ++i) {
+        const int m = m_base + row0 + 32 * i;
+        a_ok[i] = m < p.M;
+        if (MODE == 0) {
+            a_off[i] = (long long)m;
+        } else {
+            const int hw = p.Hout * p.Wout;
+            const int b = m / hw, rem = m - b * hw;
+            const int oy = rem / p.Wout;
+            a_b[i] = b; a_y[i] = oy * p.stride - 1; a_x[i] = (rem - oy * p.Wout) * p.stride - 1;
         }
     }
+    const half_t* wptr = Wb + (long long)(n_base + row0) * p.K + schunk;
+    const int nk_all = p.K >> 6;
+    const int kt0 = (int)((long long)blockIdx.y * nk_all / p.splits);
+    const int kt1 = (int)((long long)(blockIdx.y + 1) * nk_all / p.splits);
+
+    auto issue_tile = [&](int kt, int buf) {
+        char* xs = smem + buf * BUF + wave * 8 * 128;
+        char* ws = xs + XBYTES;
+        if (MODE == 0) {
+            const int k0 = kt << 6;
+            const bool second = (A2b != nullptr) && (k0 >= p.K1);
+            const half_t* base = second ? A2b : Ab;
+            const long long ld = second ? p.lda2 : p.lda;
+            const int kk = (second ? k0 - p.K1 : k0) + schunk;
+#pragma unroll
+            for (int i = 0; i < RA; ++i) {
+                const half_t* src = a_ok[i] ? base + a_off[i] * ld + kk : g_zero_page;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(xs + i * 32 * 128), 16, 0, 0);
+            }
+        } else {
+            const int cpt = p.Cin >> 6;
+            const int tap = kt / cpt;
+            const int c0 = ((kt - tap * cpt) << 6) + schunk;
+            const int dy = tap / 3, dx = tap - dy * 3;
+            const int Hl = p.ups ? p.Hin * 2 : p.Hin, Wl = p.ups ? p.Win * 2 : p.Win;
+#pragma unroll
+            for (int i = 0; i < RA; ++i) {
+                int iy = a_y[i] + dy, ix = a_x[i] + dx;
+                const bool ok = a_ok[i] && iy >= 0 && iy < Hl && ix >= 0 && ix < Wl;
+                if (p.ups) { iy >>= 1; ix >>= 1; }
+                const long long off = ((long long)(a_b[i] * p.Hin + iy) * p.Win + ix) * p.Cin + c0;
+                const half_t* src = ok ? Ab + off : g_zero_page;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(xs + i * 32 * 128), 16, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < RW; ++i) {
+            const half_t* src = wptr + (long long)(32 * i) * p.K + (kt << 6);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(ws + i * 32 * 128), 16, 0, 0);
+        }
+    };
+
+    f4 acc[TN][TM];
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b) acc[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fq = lane >> 4;
+
+#pragma unroll
+    for (int s = 0; s < S - 1; ++s)
+        if (kt0 + s < kt1) issue_tile(kt0 + s, s);
+
+    int buf = 0;
+    for (int kt = kt0; kt < kt1; ++kt) {
+        // tile kt must have landed; up to min(S-2, tiles issued after kt) newer tiles may stay in flight
+        const int newer = kt1 - 1 - kt;
+        if (S >= 4 && newer >= 2) wait_vmcnt<(S >= 4 ? 2 : 0) * LPT>();
+        else if (S >= 3 && newer >= 1) wait_vmcnt<(S >= 3 ? 1 : 0) * LPT>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kt + S - 1 < kt1) issue_tile(kt + S - 1, (buf + S - 1) % S);
+
+        const char* xs = smem + buf * BUF + (wm * (BM / 2)) * 128;
+        const char* ws = smem + buf * BUF + XBYTES + (wn * (BN / 2)) * 128;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            h8 xf[TM], wf[TN];
+            const int c = kk * 4 + fq;
+#pragma unroll
+            for (int b = 0; b < TM; ++b) {
+                const int r = b * 16 + frow;
+                xf[b] = *reinterpret_cast<const h8*>(xs + r * 128 + ((c ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int a = 0; a < TN; ++a) {
+                const int r = a * 16 + frow;
+                wf[a] = *reinterpret_cast<const h8*>(ws + r * 128 + ((c ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int a = 0; a < TN; ++a)
+#pragma unroll
+                for (int b = 0; b < TM; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[a], xf[b], acc[a][b], 0, 0, 0);
+        }
+        buf = (buf + 1 == S) ? 0 : buf + 1;
+    }
+    igemm_epilogue<BM, BN>(p, acc, m_base, n_base, wm, wn, frow, fq, z);
+}
+
+// Split-K combine: fixed-order sum of the fp32 slabs (bit-reproducible) + the epilogue of the main kernel.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(IgemmParams p) {
+    const long long i4 = (long long)blockIdx.x * 256 + threadIdx.x;      // index of a 4-channel group
+    const int n4 = p.N >> 2;
+    if (i4 >= (long long)p.M * n4) return;
+    const int m = (int)(i4 / n4), n = (int)(i4 - (long long)m * n4) * 4;
+    const long long slab = (long long)p.M * p.N;
+    const float* src = p.ws + (long long)m * p.N + n;
+    f4 v = *reinterpret_cast<const f4*>(src);
+    for (int s = 1; s < p.splits; ++s) {
+        f4 t = *reinterpret_cast<const f4*>(src + s * slab);
+        v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
+    }
+    if (p.bias) { h4 t = *reinterpret_cast<const h4*>(p.bias + n);
+        v[0] += (float)t[0]; v[1] += (float)t[1]; v[2] += (float)t[2]; v[3] += (float)t[3]; }
+    if (p.rowadd) { h4 t = *reinterpret_cast<const h4*>(p.rowadd + (long long)(m / p.rows_per_batch) * p.ld_rowadd + n);
+        v[0] += (float)t[0]; v[1] += (float)t[1]; v[2] += (float)t[2]; v[3] += (float)t[3]; }
+    v[0] *= p.out_scale; v[1] *= p.out_scale; v[2] *= p.out_scale; v[3] *= p.out_scale;
+    if (p.res) { h4 t = *reinterpret_cast<const h4*>(p.res + (long long)m * p.ldr + n);
+        v[0] += (float)t[0]; v[1] += (float)t[1]; v[2] += (float)t[2]; v[3] += (float)t[3]; }
+    h4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+    *reinterpret_cast<h4*>(p.out + (long long)m * p.ldo + n) = o;
 }
 
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BN, int MODE>
-static int launch_cfg(IgemmParams& p, int batch, hipStream_t s) {
-    p.mtiles = (p.M + BM - 1) / BM;
-    p.ntiles = p.N / BN;
-    const int smem = 2 * (BM + BN) * 128;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, MODE>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        attr_set = true;
-    }
-    dim3 grid(p.mtiles * p.ntiles, 1, batch);
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, MODE>), grid, dim3(256), smem, s, p);
-    LCM_CHECK_LAUNCH("igemm");
+static float* g_ws[16] = {};
+static long long g_ws_bytes[16] = {};
+
+extern "C" int lcm_set_workspace(void* ptr, int64_t bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { lcm_set_error("set_workspace: no device"); return LCM_ENODEV; }
+    g_ws[dev] = (float*)ptr;
+    g_ws_bytes[dev] = ptr ? bytes : 0;
+    return LCM_OK;
+}
+// Tile + split-K selection.  Candidates in order of per-FLOP efficiency (128x128, 128x64, 64x128, 64x64);
+// split-K (deterministic slab reduce) tops a launch up to >= ~1.5 workgroups per CU when the output alone
+// has too few tiles (deep-K, small-M layers: the low-resolution UNet levels at batch 1).
+struct TilePick { int bm, bn, splits; };
+static int g_target_wgs = 384, g_max_splits = 16, g_min_wgs = 256;
+static int g_variant = 2;      // 0: register-staged double buffer (v1); 2/3/4: LDS-DMA pipeline with that many stages
+
+extern "C" int lcm_set_kernel_variant(int variant) {
+    if (variant != 0 && variant != 2 && variant != 3 && variant != 4) { lcm_set_error("kernel_variant: %d", variant); return LCM_EINVAL; }
+    g_variant = variant;
     return LCM_OK;
 }
 
-// tile selection: the largest tile that still gives >= 2 workgroups per CU; else the most tiles
-static int pick_tile(int M, int N, int batch) {
-    const bool n128 = (N % 128) == 0;
-    auto tiles = [&](int bm, int bn) { return (long long)((M + bm - 1) / bm) * (N / bn) * batch; };
-    if (n128 && M >= 128 && tiles(128, 128) >= 512) return 128 * 1000 + 128;
-    if (M >= 128 && tiles(128, 64) >= 512) return 128 * 1000 + 64;
-    if (n128 && M > 64 && M < 128) return 64 * 1000 + 128;
-    return 64 * 1000 + 64;
+extern "C" int lcm_set_tuning(int target_wgs, int max_splits, int min_wgs) {
+    if (target_wgs > 0) g_target_wgs = target_wgs;
+    if (max_splits > 0) g_max_splits = max_splits;
+    if (min_wgs > 0) g_min_wgs = min_wgs;
+    return LCM_OK;
 }
 
-extern "C" int lcm_gemm_tile_config(int M, int N, int batch) { return pick_tile(M, N, batch); }
+static TilePick pick_tile(int M, int N, int K, int batch, long long ws_bytes, bool allow_split) {
+    const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
+    const int nk = K >> 6;
+    TilePick best = {64, 64, 1};
+    long long best_wgs = -1;
+    for (int c = 0; c < 4; ++c) {
+        const int bm = cand[c][0], bn = cand[c][1];
+        if (N % bn) continue;
+        if (bm == 128 && M < 128) continue;
+        if (bm == 64 && bn == 128 && M >= 128) continue;
+        const long long tiles = (long long)((M + bm - 1) / bm) * (N / bn) * batch;
+        int splits = 1;
+        if (allow_split && batch == 1 && tiles < g_min_wgs && nk >= 16) {
+            splits = (int)((g_target_wgs + tiles - 1) / tiles);
+            if (splits > nk / 8) splits = nk / 8;
+            if (splits > g_max_splits) splits = g_max_splits;
+            while (splits > 1 && (long long)splits * M * N * 4 > ws_bytes) --splits;
+            if (splits < 1) splits = 1;
+        }
+        const long long wgs = tiles * splits;
+        if (wgs >= g_min_wgs) return {bm, bn, splits};
+        if (wgs > best_wgs) { best_wgs = wgs; best = {bm, bn, splits}; }
+    }
+    return best;
+}
+
+extern "C" int lcm_gemm_tile_config(int M, int N, int batch) {
+    TilePick t = pick_tile(M, N, 64, batch, 0, false);
+    return t.bm * 1000 + t.bn;
+}
+
+template <int BM, int BN, int MODE, int S>
+static int launch_v2(IgemmParams& p, dim3 grid, hipStream_t s) {
+    constexpr int smem = S * (BM + BN) * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<BM, BN, MODE, S>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((igemm2_kernel<BM, BN, MODE, S>), grid, dim3(256), smem, s, p);
+    return 0;
+}
+
+template <int BM, int BN, int MODE>
+static int launch_cfg(IgemmParams& p, int batch, int splits, hipStream_t s) {
+    p.mtiles = (p.M + BM - 1) / BM;
+    p.ntiles = p.N / BN;
+    p.splits = splits;
+    dim3 grid(p.mtiles * p.ntiles, splits, batch);
+    int variant = g_variant;
+    if (variant == 4 && BM + BN > 192) variant = 3;      // 4 x 32 KiB stages only for the small tiles
+    if (variant == 0) {
+        const int smem = 2 * (BM + BN) * 128;
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, MODE>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((igemm_kernel<BM, BN, MODE>), grid, dim3(256), smem, s, p);
+    } else if (variant == 2) {
+        launch_v2<BM, BN, MODE, 2>(p, grid, s);
+    } else if (variant == 3) {
+        launch_v2<BM, BN, MODE, 3>(p, grid, s);
+    } else {
+        launch_v2<BM, BN, MODE, 4>(p, grid, s);
+    }
+    LCM_CHECK_LAUNCH("igemm");
+    if (splits > 1) {
+        const long long n4 = (long long)p.M * (p.N / 4);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, p);
+        LCM_CHECK_LAUNCH("splitk_reduce");
+    }
+    return LCM_OK;
+}
 
 template <int MODE>
 static int launch_igemm(IgemmParams& p, int batch, hipStream_t s) {
-    switch (pick_tile(p.M, p.N, batch)) {
-        case 128128: return launch_cfg<128, 128, MODE>(p, batch, s);
-        case 128064: return launch_cfg<128, 64, MODE>(p, batch, s);
-        case 64128: return launch_cfg<64, 128, MODE>(p, batch, s);
-        default: return launch_cfg<64, 64, MODE>(p, batch, s);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    p.ws = (dev >= 0 && dev < 16) ? g_ws[dev] : nullptr;
+    const long long wsb = p.ws ? g_ws_bytes[dev] : 0;
+    const TilePick t = pick_tile(p.M, p.N, p.K, batch, wsb, p.ws != nullptr && p.epi == 0);
+    const int code = t.bm * 1000 + t.bn;
+    switch (code) {
+        case 128128: return launch_cfg<128, 128, MODE>(p, batch, t.splits, s);
+        case 128064: return launch_cfg<128, 64, MODE>(p, batch, t.splits, s);
+        case 64128: return launch_cfg<64, 128, MODE>(p, batch, t.splits, s);
+        default: return launch_cfg<64, 64, MODE>(p, batch, t.splits, s);
     }
 }
 

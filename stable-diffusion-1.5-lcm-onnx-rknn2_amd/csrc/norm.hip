@@ -13,7 +13,6 @@
 //   3. gn_apply:    y = silu((x - mean) * rstd * gamma + beta), written as ONE concatenated tensor.
 #include "common.h"
 
-#define GN_ROWS 64          // rows of HW per stats workgroup
 #define GN_MAXC 2560
 #define GN_LDS_FLOATS 5120  // max(nrl * C, C) * 2
 
@@ -25,7 +24,8 @@ __device__ __forceinline__ h8 load_cat8(const half_t* x, int C1, const half_t* x
 
 __global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* __restrict__ x, int C1,
                                                        const half_t* __restrict__ x2, int C2,
-                                                       float* __restrict__ part, int HW, int groups, int nchunk) {
+                                                       float* __restrict__ part, int HW, int groups, int nchunk,
+                                                       int GN_ROWS) {
     __shared__ float red[GN_LDS_FLOATS];
     const int C = C1 + C2, ncc = C >> 3, cpg = C / groups;
     const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
@@ -124,11 +124,18 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict_
     }
 }
 
-static inline int gn_nchunk(int HW) { return (HW + GN_ROWS - 1) / GN_ROWS; }
+// rows of HW per stats workgroup: aim for ~1024 workgroups per launch, at least 16 rows each
+static inline int gn_rows(int B, int HW) {
+    long long r = ((long long)B * HW + 1023) / 1024;
+    if (r < 16) r = 16;
+    if (r > 4096) r = 4096;
+    return (int)r;
+}
+static inline int gn_nchunk(int B, int HW) { const int r = gn_rows(B, HW); return (HW + r - 1) / r; }
 
 extern "C" int64_t lcm_groupnorm_ws_bytes(int B, int HW, int C, int groups) {
     (void)C;
-    return ((int64_t)B * gn_nchunk(HW) * groups * 2 + (int64_t)B * groups * 2) * 4;
+    return ((int64_t)B * gn_nchunk(B, HW) * groups * 2 + (int64_t)B * groups * 2) * 4;
 }
 
 extern "C" int lcm_groupnorm_f16(const void* x, int C1, const void* x2, int C2, const void* gamma,
@@ -140,16 +147,19 @@ extern "C" int lcm_groupnorm_f16(const void* x, int C1, const void* x2, int C2, 
     LCM_REQUIRE(B > 0 && HW > 0 && groups > 0 && groups <= 64, "groupnorm: bad shape B=%d HW=%d G=%d", B, HW, groups);
     LCM_REQUIRE(C1 % 8 == 0 && C2 % 8 == 0 && C % groups == 0 && C <= GN_MAXC, "groupnorm: bad channels %d+%d", C1, C2);
     hipStream_t s = (hipStream_t)stream;
-    const int nchunk = gn_nchunk(HW);
+    const int nchunk = gn_nchunk(B, HW);
     float* part = (float*)ws;
     float* stats = part + (long long)B * nchunk * groups * 2;
     hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, B), dim3(256), 0, s, (const half_t*)x, C1, (const half_t*)x2, C2,
-                       part, HW, groups, nchunk);
+                       part, HW, groups, nchunk, gn_rows(B, HW));
     LCM_CHECK_LAUNCH("gn_stats");
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * groups), dim3(64), 0, s, part, stats, nchunk, groups,
                        1.0f / ((float)HW * (float)(C / groups)), eps);
     LCM_CHECK_LAUNCH("gn_finalize");
-    const int rows_per_wg = max(1, 2048 / (C >> 3));   // ~8 vectors per thread
+    // 1..8 vectors per thread: aim for >= 1024 workgroups on small tensors
+    long long vec_per_wg = (long long)B * HW * (C >> 3) / 1024;
+    vec_per_wg = vec_per_wg < 256 ? 256 : (vec_per_wg > 2048 ? 2048 : vec_per_wg);
+    const int rows_per_wg = max(1, (int)(vec_per_wg / (C >> 3)));
     hipLaunchKernelGGL(gn_apply_kernel, dim3((HW + rows_per_wg - 1) / rows_per_wg, B), dim3(256), 0, s,
                        (const half_t*)x, C1, (const half_t*)x2, C2, (const half_t*)gamma, (const half_t*)beta, stats,
                        (half_t*)out, HW, groups, silu, rows_per_wg);

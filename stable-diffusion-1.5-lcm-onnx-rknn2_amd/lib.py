@@ -51,6 +51,9 @@ _SIGS = {
     "lcm_graph_destroy": [_vp],
     "lcm_gemm_tile_config": [_i, _i, _i],
     "lcm_debug_spin": [_i, _vp],
+    "lcm_set_workspace": [_vp, _i64],
+    "lcm_set_tuning": [_i, _i, _i],
+    "lcm_set_kernel_variant": [_i],
     "lcm_device_info": [_i, C.c_char_p, _i, C.POINTER(_i), C.POINTER(C.c_uint64)],
 }
 EXPORTS = tuple(sorted(list(_SIGS) + ["lcm_last_error", "lcm_version", "lcm_groupnorm_ws_bytes"]))

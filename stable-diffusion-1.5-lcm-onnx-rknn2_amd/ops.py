@@ -163,6 +163,20 @@ def latents_pool8(lat, out, B, h, w):
     return out
 
 
+def set_workspace(t):
+    """Register an fp32 scratch tensor for deterministic split-K on the current device (None disables)."""
+    L = _lib.load()
+    _lib.check(L.lcm_set_workspace(_p(t), 0 if t is None else t.numel() * t.element_size()), "lcm_set_workspace")
+
+
+def set_tuning(target_wgs=0, max_splits=0, min_wgs=0):
+    _lib.check(_lib.load().lcm_set_tuning(int(target_wgs), int(max_splits), int(min_wgs)), "lcm_set_tuning")
+
+
+def set_kernel_variant(v):
+    _lib.check(_lib.load().lcm_set_kernel_variant(int(v)), "lcm_set_kernel_variant")
+
+
 def debug_spin(usec):
     _lib.check(_lib.load().lcm_debug_spin(int(usec), _stream()), "lcm_debug_spin")
 

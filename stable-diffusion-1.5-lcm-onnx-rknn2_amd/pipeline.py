@@ -11,6 +11,8 @@ launched, so the captured graph is RNG-free and replays for any seed.
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -82,6 +84,10 @@ class LcmHipPipeline:
         self.use_graph = use_graph
         self._plans = {}
         self.stream = torch.cuda.Stream(device=self.device)
+        # fp32 scratch for deterministic split-K of the deep-K / small-M layers (low-res UNet levels at batch 1)
+        self._splitk_ws = torch.empty(int(os.environ.get("LCM_SPLITK_WS_MB", "64")) << 18, dtype=torch.float32,
+                                      device=self.device)
+        ops.set_workspace(self._splitk_ws)
 
     # ------------------------------------------------------------------------------------------
     def _enqueue(self, P: _Plan, guidance: float, want_float=False, taps=None):

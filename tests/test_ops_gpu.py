@@ -110,6 +110,84 @@ def test_conv3x3(B, H, W, Cin, Cout, stride, ups):
     close(from_nhwc(out, B, Ho, Wo), ref, what="conv3x3")
 
 
+@pytest.mark.parametrize("B,H,Cin,Cout", [(1, 8, 1280, 1280), (1, 16, 640, 1280), (1, 32, 640, 640), (1, 64, 320, 320),
+                                         (2, 8, 2560, 1280)])
+def test_conv3x3_splitk(B, H, Cin, Cout):
+    """Deep-K / small-M layers run split-K once a workspace is registered; result must match the unsplit one."""
+    x = rnd(B, Cin, H, H, seed=1)
+    w = rnd(Cout, Cin, 3, 3, seed=2, scale=(9 * Cin) ** -0.5)
+    b, radd, res = rnd(Cout, seed=3), rnd(B, Cout, seed=4), rnd(B, Cout, H, H, seed=5)
+    ref = F.conv2d(x.float(), w.float(), b.float(), padding=1) + radd.float()[:, :, None, None] + res.float()
+    args = (to_nhwc(x).to(DEV), pack3x3(w).to(DEV))
+    kw = dict(bias=b.to(DEV), rowadd=radd.to(DEV), res=to_nhwc(res).to(DEV))
+    o1 = torch.empty(B * H * H, Cout, dtype=torch.float16, device=DEV)
+    o2 = torch.empty_like(o1)
+    ops.set_workspace(None)
+    ops.conv3x3(*args, o1, B, H, H, Cin, Cout, **kw)
+    ws = torch.empty(16 << 20, dtype=torch.float32, device=DEV)
+    ops.set_workspace(ws)
+    try:
+        ops.conv3x3(*args, o2, B, H, H, Cin, Cout, **kw)
+        ops.conv3x3(*args, o1, B, H, H, Cin, Cout, **kw)     # determinism of the slab reduce
+        torch.cuda.synchronize()
+    finally:
+        ops.set_workspace(None)
+    close(from_nhwc(o2, B, H, H), ref, what="conv3x3 split-K")
+    assert torch.equal(o1, o2)
+
+
+@pytest.mark.parametrize("variant", [2, 3, 4])
+def test_contraction_kernel_variants(variant):
+    """The LDS-DMA pipeline variants must reproduce the register-staged kernel bit for bit
+    (same MFMA contraction order), on conv (borders, upsample, stride 2, m-tail) and split-source gemm."""
+    cases = [(2, 12, 20, 128, 192, 1, 0), (1, 9, 7, 64, 64, 2, 0), (1, 6, 10, 192, 128, 1, 1), (1, 64, 64, 320, 320, 1, 0),
+             (1, 8, 8, 1280, 1280, 1, 0)]
+    ws = torch.empty(16 << 20, dtype=torch.float32, device=DEV)
+    try:
+        for (B, H, W, Cin, Cout, stride, ups) in cases:
+            x = to_nhwc(rnd(B, Cin, H, W, seed=1)).to(DEV)
+            w = pack3x3(rnd(Cout, Cin, 3, 3, seed=2, scale=(9 * Cin) ** -0.5)).to(DEV)
+            b = rnd(Cout, seed=3).to(DEV)
+            Ho, Wo = ((2 * H, 2 * W) if ups else ((H + 1) // 2, (W + 1) // 2) if stride == 2 else (H, W))
+            outs = []
+            for v in (0, variant):
+                ops.set_kernel_variant(v)
+                ops.set_workspace(ws)
+                o = torch.empty(B * Ho * Wo, Cout, dtype=torch.float16, device=DEV)
+                ops.conv3x3(x, w, o, B, H, W, Cin, Cout, bias=b, stride=stride, ups=ups)
+                outs.append(o)
+            torch.cuda.synchronize()
+            assert torch.equal(outs[0], outs[1]), f"variant {variant} differs on conv {(B, H, W, Cin, Cout, stride, ups)}"
+        M, N, K1, K2 = 300, 320, 640, 320
+        a1, a2 = rnd(M, K1, seed=1).to(DEV), rnd(M, K2, seed=2).to(DEV)
+        w = rnd(N, K1 + K2, seed=3, scale=0.03).to(DEV)
+        outs = []
+        for v in (0, variant):
+            ops.set_kernel_variant(v)
+            o = torch.empty(M, N, dtype=torch.float16, device=DEV)
+            ops.gemm(a1, w, o, a2=a2)
+            outs.append(o)
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0], outs[1])
+    finally:
+        ops.set_kernel_variant(2)      # library default
+        ops.set_workspace(None)
+
+
+def test_gemm_splitk():
+    M, N, K = 64, 1280, 5120
+    a, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+    out = torch.empty(M, N, dtype=torch.float16, device=DEV)
+    ws = torch.empty(8 << 20, dtype=torch.float32, device=DEV)
+    ops.set_workspace(ws)
+    try:
+        ops.gemm(a.to(DEV), w.to(DEV), out, bias=b.to(DEV))
+        torch.cuda.synchronize()
+    finally:
+        ops.set_workspace(None)
+    close(out, F.linear(a.float(), w.float(), b.float()), what="gemm split-K")
+
+
 @pytest.mark.parametrize("pre", [False, True])
 def test_conv_c4(pre):
     B, H, W, Cout = 2, 24, 16, 320

@@ -31,8 +31,66 @@ def rnd(*s):
     return torch.randn(*s, device=DEV, dtype=torch.float16)
 
 
+def splitk_sweep():
+    """B=1 UNet conv shapes: no split vs split-K under a few heuristics."""
+    ws = torch.empty(64 << 18, dtype=torch.float32, device=DEV)
+    shapes = ((64, 320, 320), (64, 640, 320), (32, 640, 640), (32, 1280, 640), (16, 1280, 1280), (16, 2560, 1280),
+              (8, 1280, 1280), (8, 2560, 1280))
+    cfgs = (("nosplit", None), ("t384/s16/m256", (384, 16, 256)), ("t256/s8/m256", (256, 8, 256)),
+            ("t512/s32/m256", (512, 32, 256)), ("t384/s16/m160", (384, 16, 160)), ("t768/s32/m384", (768, 32, 384)))
+    for (H, Cin, Cout) in shapes:
+        x, w = rnd(H * H, Cin), rnd(Cout, 9 * Cin)
+        o = torch.empty(H * H, Cout, device=DEV, dtype=torch.float16)
+        line = f"conv B1 {H}x{H} {Cin}->{Cout}:"
+        for name, cfg in cfgs:
+            if cfg is None:
+                ops.set_workspace(None)
+            else:
+                ops.set_workspace(ws)
+                ops.set_tuning(*cfg)
+            t = timeit(lambda: ops.conv3x3(x, w, o, 1, H, H, Cin, Cout))
+            line += f"  {name} {t * 1e6:.1f}us"
+        print(line)
+    ops.set_workspace(None)
+    ops.set_tuning(384, 16, 256)
+
+
+def variant_sweep():
+    ws = torch.empty(64 << 18, dtype=torch.float32, device=DEV)
+    ops.set_workspace(ws)
+    convs = ((1, 64, 320, 320), (1, 16, 1280, 1280), (1, 8, 1280, 1280), (8, 64, 320, 320), (8, 32, 640, 640), (8, 16, 1280, 1280),
+             (8, 8, 1280, 1280), (8, 64, 960, 320), (1, 128, 512, 512), (1, 256, 256, 256), (1, 512, 128, 128), (8, 128, 512, 512))
+    gemms = ((4096, 320, 320), (4096, 2560, 320), (4096, 320, 1280), (1024, 640, 640), (256, 1280, 1280), (32768, 320, 320),
+             (32768, 2560, 320), (32768, 320, 1280), (8192, 5120, 640))
+    for (B, H, Cin, Cout) in convs:
+        x, w = rnd(B * H * H, Cin), rnd(Cout, 9 * Cin)
+        o = torch.empty(B * H * H, Cout, device=DEV, dtype=torch.float16)
+        fl = 2.0 * B * H * H * Cout * 9 * Cin
+        line = f"conv B{B} {H}x{H} {Cin}->{Cout}:"
+        for v in (0, 2, 3, 4):
+            ops.set_kernel_variant(v)
+            t = timeit(lambda: ops.conv3x3(x, w, o, B, H, H, Cin, Cout))
+            line += f"  v{v} {t * 1e6:7.1f}us {fl / t / 1e12:6.0f}TF"
+        print(line)
+    for (M, N, K) in gemms:
+        a, w = rnd(M, K), rnd(N, K)
+        o = torch.empty(M, N, device=DEV, dtype=torch.float16)
+        line = f"gemm M{M} N{N} K{K}:"
+        for v in (0, 2, 3, 4):
+            ops.set_kernel_variant(v)
+            t = timeit(lambda: ops.gemm(a, w, o))
+            line += f"  v{v} {t * 1e6:7.1f}us {2.0 * M * N * K / t / 1e12:6.0f}TF"
+        print(line)
+    ops.set_kernel_variant(2)
+    ops.set_workspace(None)
+
+
 def main():
     print("device", torch.cuda.get_device_name(0))
+    if len(sys.argv) > 1 and sys.argv[1] == "splitk":
+        return splitk_sweep()
+    if len(sys.argv) > 1 and sys.argv[1] == "variants":
+        return variant_sweep()
     rows = []
     for B in (1, 8):
         for (H, Cin, Cout) in ((64, 320, 320), (32, 640, 640), (16, 1280, 1280), (8, 1280, 1280), (64, 960, 320),
