@@ -117,7 +117,11 @@ def test_batched_requests_match_single_requests(state):
     batched = hip.generate(pe, seeds, 128, 128, 4, 1.0)
     for i, s in enumerate(seeds):
         one = hip.generate(pe[i:i + 1], [s], 128, 128, 4, 1.0)
-        assert np.array_equal(one["rgb"][0], batched["rgb"][i]), f"request {i} differs in the batch"
+        # split-K factors depend on the batch size, so the fp32 summation order (not the values summed) may
+        # differ between a batched and a single run: equal up to fp16 rounding, not necessarily bit for bit
+        d = np.abs(one["rgb"][0].astype(int) - batched["rgb"][i].astype(int))
+        assert d.max() <= 2 and (d > 0).mean() < 0.05, f"request {i} differs in the batch: max {d.max()}"
+        assert np.abs(one["latents"][0] - batched["latents"][i]).max() < 0.05
 
 
 def test_latents_blob_matches_oracle_pooling(state):
