@@ -71,6 +71,24 @@ int lcm_conv3x3_f16(const void* in, const void* W, const void* bias,
                     const void* rowadd, int ld_rowadd, const void* res, void* out,
                     int B, int Hin, int Win, int Cin, int Cout, int stride, int ups, void* stream);
 
+/* ---- fused GroupNorm(+SiLU) -> 3x3 convolution, stride 1 (ResnetBlock2D norm1->act->conv1, norm2->act->conv2) ----
+ * LDS-halo implicit GEMM (csrc/conv_halo.hip).  Input = channel concat [in | in2] (in2 NULL: single source; fused
+ * torch.cat of the skip).  gn_scale/gn_shift: fp32 [B][C1+C2] from lcm_groupnorm_affine_f16 (NULL: plain conv);
+ * silu=1 applies SiLU after the affine; zero padding is applied AFTER the normalisation, as in the reference
+ * graph.  ups=1 reads the (raw) input through a nearest-2x upsample.  Epilogue as lcm_gemm_f16.
+ * Preconditions: C1, C2, Cout multiples of 64.
+ */
+int lcm_conv3x3_gn_f16(const void* in, int C1, const void* in2, int C2, const void* gn_scale, const void* gn_shift,
+                       int silu, const void* W, const void* bias, const void* rowadd, int ld_rowadd, const void* res,
+                       void* out, int B, int Hin, int Win, int Cout, int ups, void* stream);
+/* GroupNorm statistics folded into per-(image, channel) fp32 scale/shift tables [B][C1+C2] for the call above;
+ * ws as for lcm_groupnorm_f16. */
+int lcm_groupnorm_affine_f16(const void* x, int C1, const void* x2, int C2, const void* gamma, const void* beta,
+                             void* scale_out, void* shift_out, int B, int HW, int groups, float eps, void* ws,
+                             void* stream);
+/* 1 (default): stride-1 3x3 convolutions use the LDS-halo kernel; 0: the row-gather implicit GEMM everywhere */
+int lcm_set_conv_impl(int impl);
+
 /* ---- 3x3 convolution from the fp32 NCHW latent (UNet conv_in; VAE post_quant_conv+decoder.conv_in) ----
  * in: fp32 [B,4,H,W]; optional pre-transform z = pre_w(4x4 fp32, row=out) * (in * in_scale) + pre_b
  * (AutoencoderKL: latents / scaling_factor -> post_quant_conv, backends/rknnlcm.py:614).

@@ -1,0 +1,258 @@
+// 3x3 convolution (stride 1, pad 1) as an implicit GEMM with an LDS-staged input halo tile, optionally with
+// GroupNorm-apply + SiLU fused into the staging pass and the skip concat / nearest-2x upsample fused into the
+// loader.  gfx950 (MI355X).
+//
+// Replaces ResnetBlock2D.{norm1->silu->conv1, norm2->silu->conv2} and Upsample2D.conv of UNet2DConditionModel /
+// AutoencoderKL.decode (reached from backends/cuda_worker.py:221-229).
+//
+// One workgroup = a TH x TW patch of output pixels (BM = TH*TW = 128 or 64) x BN output channels.  K is walked
+// channel-chunk major: for each 64-channel chunk the (TH+2) x (TW+2) input halo is staged ONCE into LDS
+// (128-byte rows, XOR-swizzled; out-of-image pixels are zeros, so no masking later) and reused by all 9 taps;
+// only the 64 x BN weight slice of the tap is streamed per K-step (LDS-DMA).  Against the row-gather igemm this
+// cuts global->LDS traffic per K-step from (BM+BN) to (BN + 1.4*BM/9) rows and removes the per-tap address VALU.
+// With XFORM the halo goes through registers: y = silu(x * scale[b][c] + shift[b][c]) (the GroupNorm affine
+// folded per (image, channel)) is applied once per staged element -- 1.4x per element per n-tile instead of
+// 9x -- and the normalised tensor is never written to HBM.
+// Single-buffered LDS (<= 40 KiB): 4 workgroups per CU cover the staging latency (measured faster than a
+// deeper pipeline at 2 workgroups per CU for the large grids this kernel is used on).
+// Wave layout, MFMA (16x16x32 f16, weights as the A operand) and epilogue are those of igemm.hip.
+#include "igemm_common.h"
+
+struct HaloParams {
+    IgemmParams g;          // A/A2 = inputs, W, bias, rowadd, res, out, M,N,K, ldo, ldr, Hin/Win (physical), Cin, ups, splits, ws
+    int C1;                 // channels taken from g.A; the remaining Cin - C1 from g.A2
+    const float* gn_scale;  // [B][Cin] fp32 or null
+    const float* gn_shift;
+    int silu;
+    int H, W;               // logical (post-upsample) image size == output size
+    int tiles_y, tiles_x;
+};
+
+static __device__ __attribute__((aligned(256))) half_t g_zero_page_h[128];
+
+template <int TH, int TW, int BN, int XFORM>
+__global__ __launch_bounds__(256, 3) void conv_halo_kernel(HaloParams hp) {
+    constexpr int BM = TH * TW;
+    constexpr int TM = BM / 32, TN = BN / 32, RW = BN / 32;
+    constexpr int HWD = TW + 2, HROWS = (TH + 2) * HWD, HROWS_PAD = (HROWS + 7) / 8 * 8;
+    constexpr int NV = (HROWS_PAD * 8 + 255) / 256;      // halo 16-byte vectors per thread
+    constexpr int XBYTES = HROWS_PAD * 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* xs = smem;
+    char* wsm = smem + XBYTES;
+
+    const IgemmParams& p = hp.g;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, wn = wave >> 1;
+    const int tile = xcd_remap(blockIdx.x, p.mtiles * p.ntiles);
+    const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
+    const int per_img = hp.tiles_y * hp.tiles_x;
+    const int bimg = mt / per_img, tr = mt - bimg * per_img;
+    const int ty = tr / hp.tiles_x, tx = tr - ty * hp.tiles_x;
+    const int y0 = ty * TH, x0 = tx * TW;
+    const int n_base = nt * BN;
+    const int C2 = p.Cin - hp.C1;
+
+    // ---- per-thread halo vector descriptors (constant over the K loop) ----
+    int h_pix[NV];       // physical pixel index (b*Hin + py)*Win + px, or -1 (zero fill)
+    const int pos = tid & 7;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int v = tid + 256 * i;
+        const int hr = v >> 3;
+        const int hy = hr / HWD, hx = hr - hy * HWD;
+        int ly = y0 - 1 + hy, lx = x0 - 1 + hx;
+        const bool ok = hr < HROWS && ly >= 0 && ly < hp.H && lx >= 0 && lx < hp.W;
+        if (p.ups) { ly >>= 1; lx >>= 1; }
+        h_pix[i] = ok ? (bimg * p.Hin + ly) * p.Win + lx : -1;
+    }
+    // glds path: LDS position is lane-linear (v*16) and the SOURCE chunk is swizzled;
+    // register path: the source chunk is the thread's (tid&7) and the LDS position is swizzled:
+    //   row hr = (tid>>3) + 32*i, so (hr & 7) = (tid>>3) & 7 for every i.
+    const int x_lds0 = (tid >> 3) * 128 + ((pos ^ ((tid >> 3) & 7)) << 4);
+    const int w_row0 = tid >> 3;
+    const int w_schunk = (pos ^ (w_row0 & 7)) * 8;
+    const half_t* wptr = p.W + (long long)(n_base + w_row0) * p.K + w_schunk;
+
+    // ---- per-lane fragment row bases ----
+    const int frow = lane & 15, fq = lane >> 4;
+    // halo row of this lane's pixel in m-tile b is affine in b: rb0 + b * (16/TW) * HWD
+    const int q0 = wm * TM * 16 + frow;
+    const int rb0 = (q0 / TW) * HWD + (q0 % TW);
+    constexpr int RB_STEP = (16 / TW) * HWD;
+
+    f4 acc[TN][TM];
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b) acc[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
+
+    const int nchunks = p.Cin >> 6;
+    const int c_begin = (int)((long long)blockIdx.y * nchunks / p.splits);
+    const int c_end = (int)((long long)(blockIdx.y + 1) * nchunks / p.splits);
+    bool first = true;
+
+    for (int c64 = c_begin; c64 < c_end; ++c64) {
+        const int cb = c64 << 6;
+        const bool second = cb >= hp.C1;
+        const half_t* src_base = second ? p.A2 : p.A;
+        const int src_ld = second ? C2 : hp.C1;
+        const int src_c = second ? cb - hp.C1 : cb;
+        for (int tap = 0; tap < 9; ++tap) {
+            if (!first) __syncthreads();          // all waves finished reading the W tile (and the halo when tap == 0)
+            first = false;
+            if (tap == 0) {
+                if (XFORM) {
+                    h8 hv[NV];
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) {
+                        h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                        if (h_pix[i] >= 0) v = *reinterpret_cast<const h8*>(src_base + (long long)h_pix[i] * src_ld + src_c + pos * 8);
+                        hv[i] = v;
+                    }
+                    const float* sc = hp.gn_scale + (long long)bimg * p.Cin + cb + pos * 8;
+                    const float* sh = hp.gn_shift + (long long)bimg * p.Cin + cb + pos * 8;
+                    float s8[8], t8[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { s8[j] = sc[j]; t8[j] = sh[j]; }
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) {
+                        if (tid + 256 * i < HROWS_PAD * 8) {
+                            h8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+                            if (h_pix[i] >= 0) {
+#pragma unroll
+                                for (int j = 0; j < 8; ++j) {
+                                    float f = (float)hv[i][j] * s8[j] + t8[j];
+                                    if (hp.silu) f = silu_f(f);
+                                    o[j] = (half_t)f;
+                                }
+                            }
+                            *reinterpret_cast<h8*>(xs + x_lds0 + i * 32 * 128) = o;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) {
+                        if ((wave + 4 * i) * 64 < HROWS_PAD * 8) {       // wave-uniform: whole 1 KiB piece in range
+                            const int hr = (tid + 256 * i) >> 3;
+                            const half_t* src = h_pix[i] >= 0
+                                ? src_base + (long long)h_pix[i] * src_ld + src_c + ((pos ^ (hr & 7)) << 3)
+                                : g_zero_page_h;
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                             (__attribute__((address_space(3))) void*)(xs + (wave + 4 * i) * 1024),
+                                                             16, 0, 0);
+                        }
+                    }
+                }
+            }
+            {   // weight slice of this tap: rows n_base.., 64 channels at (tap, cb)
+                const half_t* wsrc = wptr + (long long)tap * p.Cin + cb;
+#pragma unroll
+                for (int i = 0; i < RW; ++i)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + (long long)(32 * i) * p.K),
+                                                     (__attribute__((address_space(3))) void*)(wsm + (i * 32 + wave * 8) * 128),
+                                                     16, 0, 0);
+            }
+            __syncthreads();      // drains the LDS-DMA (vmcnt(0)) and the ds_writes, then barrier
+
+            const int dy = tap / 3, dx = tap - dy * 3;
+            const int tapoff = dy * HWD + dx;
+            const char* wsr = wsm + (wn * (BN / 2)) * 128;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                h8 xf[TM], wf[TN];
+                const int c = kk * 4 + fq;
+#pragma unroll
+                for (int b = 0; b < TM; ++b) {
+                    const int r = rb0 + b * RB_STEP + tapoff;
+                    xf[b] = *reinterpret_cast<const h8*>(xs + r * 128 + ((c ^ (r & 7)) << 4));
+                }
+#pragma unroll
+                for (int a = 0; a < TN; ++a) {
+                    const int r = a * 16 + frow;
+                    wf[a] = *reinterpret_cast<const h8*>(wsr + r * 128 + ((c ^ (r & 7)) << 4));
+                }
+#pragma unroll
+                for (int a = 0; a < TN; ++a)
+#pragma unroll
+                    for (int b = 0; b < TM; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[a], xf[b], acc[a][b], 0, 0, 0);
+            }
+        }
+    }
+
+    int m_of[TM];
+#pragma unroll
+    for (int b = 0; b < TM; ++b) {
+        const int q = (wm * TM + b) * 16 + frow;
+        const int y = y0 + q / TW, x = x0 + q % TW;
+        m_of[b] = (y < hp.H && x < hp.W) ? (bimg * hp.H + y) * hp.W + x : -1;
+    }
+    igemm_epilogue<BM, BN>(p, acc, m_of, n_base + wn * (BN / 2), fq, 0);
+}
+
+// split-K combine kernel lives in igemm.hip
+extern void lcm_launch_splitk_reduce(const IgemmParams& p, hipStream_t s);
+extern float* lcm_splitk_workspace(long long* bytes);
+extern void lcm_tuning(int* target_wgs, int* max_splits, int* min_wgs);
+
+template <int TH, int TW, int BN, int XFORM>
+static void launch_halo(HaloParams& hp, hipStream_t s) {
+    constexpr int HROWS_PAD = ((TH + 2) * (TW + 2) + 7) / 8 * 8;
+    constexpr int smem = HROWS_PAD * 128 + BN * 128;
+    hp.tiles_y = (hp.H + TH - 1) / TH;
+    hp.tiles_x = (hp.W + TW - 1) / TW;
+    hp.g.ntiles = hp.g.N / BN;
+    dim3 grid(hp.g.mtiles * hp.g.ntiles, hp.g.splits, 1);
+    hipLaunchKernelGGL((conv_halo_kernel<TH, TW, BN, XFORM>), grid, dim3(256), smem, s, hp);
+}
+
+// returns 0 when launched, 1 when the shape is not handled here (caller falls back to the row-gather igemm)
+int lcm_conv_halo_launch(HaloParams& hp, int B, hipStream_t s) {
+    IgemmParams& p = hp.g;
+    const int TW = (hp.W % 16 == 0 || hp.W > 16) ? 16 : 8;
+    int target, max_splits, min_wgs;
+    lcm_tuning(&target, &max_splits, &min_wgs);
+    long long ws_bytes = 0;
+    p.ws = lcm_splitk_workspace(&ws_bytes);
+    const int nchunks = p.Cin >> 6;
+    // candidates (BM, BN) by per-FLOP efficiency; split over channel chunks fills the chip for small images
+    const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
+    int bm = 0, bn = 0, splits = 1;
+    long long best = -1;
+    for (int c = 0; c < 4; ++c) {
+        const int cbm = cand[c][0], cbn = cand[c][1];
+        if (p.N % cbn) continue;
+        if (TW == 8 && cbm == 128) continue;
+        const int th = cbm / TW;
+        const long long mt = (long long)B * ((hp.H + th - 1) / th) * ((hp.W + TW - 1) / TW);
+        // skip tiles that would be mostly padding
+        if ((long long)mt * cbm > 2ll * p.M && cbm == 128) continue;
+        const long long tiles = mt * (p.N / cbn);
+        int sp = 1;
+        if (p.ws && tiles < min_wgs && nchunks >= 2) {
+            sp = (int)((target + tiles - 1) / tiles);
+            if (sp > nchunks) sp = nchunks;
+            if (sp > max_splits) sp = max_splits;
+            while (sp > 1 && (long long)sp * p.M * p.N * 4 > ws_bytes) --sp;
+        }
+        const long long wgs = tiles * sp;
+        if (wgs >= min_wgs) { bm = cbm; bn = cbn; splits = sp; break; }
+        if (wgs > best) { best = wgs; bm = cbm; bn = cbn; splits = sp; }
+    }
+    if (!bm) return 1;
+    const int th = bm / TW;
+    p.mtiles = B * ((hp.H + th - 1) / th) * ((hp.W + TW - 1) / TW);
+    p.splits = splits;
+    const bool xf = hp.gn_scale != nullptr;
+#define HALO_CASE(TH_, TW_, BN_)                                                           \
+    if (th == TH_ && TW == TW_ && bn == BN_) {                                             \
+        if (xf) launch_halo<TH_, TW_, BN_, 1>(hp, s); else launch_halo<TH_, TW_, BN_, 0>(hp, s); \
+    } else
+    HALO_CASE(8, 16, 128) HALO_CASE(8, 16, 64) HALO_CASE(4, 16, 128) HALO_CASE(4, 16, 64)
+    HALO_CASE(8, 8, 128) HALO_CASE(8, 8, 64) { return 1; }
+#undef HALO_CASE
+    if (splits > 1) lcm_launch_splitk_reduce(p, s);
+    return 0;
+}

@@ -15,96 +15,7 @@
 // GEGLU gate, fp16 convert) runs on 8-byte vectors with no cross-lane traffic.
 // For the 3x3 case the K loop walks (tap, 64-channel chunk); each A row is the 128 contiguous bytes of
 // one shifted input pixel (zero-filled outside the image; optional fused nearest-2x upsample).
-#include "common.h"
-
-struct IgemmParams {
-    const half_t* A;
-    const half_t* A2;
-    const half_t* W;
-    const half_t* bias;
-    const half_t* rowadd;
-    const half_t* res;
-    half_t* out;
-    int M, N, K;
-    int lda, lda2, K1;
-    int ldo, ldr, ld_rowadd, rows_per_batch;
-    int epi;
-    float out_scale;
-    long long strideA, strideW, strideO;
-    // conv
-    int Hin, Win, Cin, Hout, Wout, stride, ups;
-    int mtiles, ntiles;
-    int splits;          // split-K: blockIdx.y owns k-tiles [y*nk/splits, (y+1)*nk/splits); partials -> ws
-    float* ws;           // fp32 [splits][M][N]
-};
-
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-    // contiguous chunk of tiles per XCD (blocks are dealt round-robin over the 8 XCDs)
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-}
-
-template <int BM, int BN>
-__device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f4 (&acc)[BN / 32][BM / 32], int m_base, int n_base,
-                                               int wm, int wn, int frow, int fq, int z) {
-    constexpr int TM = BM / 32, TN = BN / 32;
-    if (p.splits > 1) {   // split-K: raw fp32 partial slab, epilogue runs in splitk_reduce_kernel
-        float* __restrict__ wsb = p.ws + (long long)blockIdx.y * p.M * p.N;
-#pragma unroll
-        for (int b = 0; b < TM; ++b) {
-            const int m = m_base + wm * (BM / 2) + b * 16 + frow;
-            if (m >= p.M) continue;
-#pragma unroll
-            for (int a = 0; a < TN; ++a) {
-                const int n = n_base + wn * (BN / 2) + a * 16 + fq * 4;
-                *reinterpret_cast<f4*>(wsb + (long long)m * p.N + n) = acc[a][b];
-            }
-        }
-        return;
-    }
-
-    // ---- epilogue: lane holds out[m = ..+frow][n = ..+fq*4 .. +3] ----
-    half_t* __restrict__ outb = p.out + z * p.strideO;
-#pragma unroll
-    for (int b = 0; b < TM; ++b) {
-        const int m = m_base + wm * (BM / 2) + b * 16 + frow;
-        if (m >= p.M) continue;
-        const half_t* radd = p.rowadd ? p.rowadd + (long long)(m / p.rows_per_batch) * p.ld_rowadd : nullptr;
-        if (p.epi == 0) {
-#pragma unroll
-            for (int a = 0; a < TN; ++a) {
-                const int n = n_base + wn * (BN / 2) + a * 16 + fq * 4;
-                f4 v = acc[a][b];
-                if (p.bias) { h4 t = *reinterpret_cast<const h4*>(p.bias + n);
-                    v[0] += (float)t[0]; v[1] += (float)t[1]; v[2] += (float)t[2]; v[3] += (float)t[3]; }
-                if (radd) { h4 t = *reinterpret_cast<const h4*>(radd + n);
-                    v[0] += (float)t[0]; v[1] += (float)t[1]; v[2] += (float)t[2]; v[3] += (float)t[3]; }
-                v[0] *= p.out_scale; v[1] *= p.out_scale; v[2] *= p.out_scale; v[3] *= p.out_scale;
-                if (p.res) { h4 t = *reinterpret_cast<const h4*>(p.res + (long long)m * p.ldr + n);
-                    v[0] += (float)t[0]; v[1] += (float)t[1]; v[2] += (float)t[2]; v[3] += (float)t[3]; }
-                h4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-                *reinterpret_cast<h4*>(outb + (long long)m * p.ldo + n) = o;
-            }
-        } else {  // GEGLU: even n-tile = value rows, odd n-tile = gate rows (16-row interleave)
-#pragma unroll
-            for (int a = 0; a < TN; a += 2) {
-                const int n = n_base + wn * (BN / 2) + a * 16 + fq * 4;      // packed row of the value
-                f4 x = acc[a][b], g = acc[a + 1][b];
-                if (p.bias) {
-                    h4 tx = *reinterpret_cast<const h4*>(p.bias + n);
-                    h4 tg = *reinterpret_cast<const h4*>(p.bias + n + 16);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) { x[j] += (float)tx[j]; g[j] += (float)tg[j]; }
-                }
-                h4 o;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = (half_t)(x[j] * gelu_erf_f(g[j]));
-                const int nout = ((n_base + wn * (BN / 2) + a * 16) >> 1) + fq * 4;
-                *reinterpret_cast<h4*>(outb + (long long)m * p.ldo + nout) = o;
-            }
-        }
-    }
-}
+#include "igemm_common.h"
 
 template <int BM, int BN, int MODE>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
@@ -236,7 +147,13 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
         __syncthreads();
     }
 
-    igemm_epilogue<BM, BN>(p, acc, m_base, n_base, wm, wn, frow, fq, z);
+    int m_of[TM];
+#pragma unroll
+    for (int b = 0; b < TM; ++b) {
+        const int m = m_base + wm * (BM / 2) + b * 16 + frow;
+        m_of[b] = m < p.M ? m : -1;
+    }
+    igemm_epilogue<BM, BN>(p, acc, m_of, n_base + wn * (BN / 2), fq, z);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -254,7 +171,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 template <int BM, int BN, int MODE, int S>
-__global__ __launch_bounds__(256, 2) void igemm2_kernel(IgemmParams p) {
+__global__ __launch_bounds__(256, S == 1 ? 4 : 2) void igemm2_kernel(IgemmParams p) {
     constexpr int RA = BM / 32, RW = BN / 32;
     constexpr int TM = BM / 32, TN = BN / 32;
     constexpr int XBYTES = BM * 128, WBYTES = BN * 128, BUF = XBYTES + WBYTES;
@@ -353,11 +270,18 @@ __global__ __launch_bounds__(256, 2) void igemm2_kernel(IgemmParams p) {
     for (int kt = kt0; kt < kt1; ++kt) {
         // tile kt must have landed; up to min(S-2, tiles issued after kt) newer tiles may stay in flight
         const int newer = kt1 - 1 - kt;
-        if (S >= 4 && newer >= 2) wait_vmcnt<(S >= 4 ? 2 : 0) * LPT>();
-        else if (S >= 3 && newer >= 1) wait_vmcnt<(S >= 3 ? 1 : 0) * LPT>();
-        else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        if (kt + S - 1 < kt1) issue_tile(kt + S - 1, (buf + S - 1) % S);
+        if (S == 1) {   // single LDS buffer: rely on 4-5 co-resident workgroups per CU to cover the load latency
+            if (kt > kt0) __builtin_amdgcn_s_barrier();      // everyone done reading the previous tile
+            issue_tile(kt, 0);
+            wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+        } else {
+            if (S >= 4 && newer >= 2) wait_vmcnt<(S >= 4 ? 2 : 0) * LPT>();
+            else if (S >= 3 && newer >= 1) wait_vmcnt<(S >= 3 ? 1 : 0) * LPT>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            if (kt + S - 1 < kt1) issue_tile(kt + S - 1, (buf + S - 1) % S);
+        }
 
         const char* xs = smem + buf * BUF + (wm * (BM / 2)) * 128;
         const char* ws = smem + buf * BUF + XBYTES + (wn * (BN / 2)) * 128;
@@ -383,7 +307,13 @@ __global__ __launch_bounds__(256, 2) void igemm2_kernel(IgemmParams p) {
         }
         buf = (buf + 1 == S) ? 0 : buf + 1;
     }
-    igemm_epilogue<BM, BN>(p, acc, m_base, n_base, wm, wn, frow, fq, z);
+    int m_of[TM];
+#pragma unroll
+    for (int b = 0; b < TM; ++b) {
+        const int m = m_base + wm * (BM / 2) + b * 16 + frow;
+        m_of[b] = m < p.M ? m : -1;
+    }
+    igemm_epilogue<BM, BN>(p, acc, m_of, n_base + wn * (BN / 2), fq, z);
 }
 
 // Split-K combine: fixed-order sum of the fp32 slabs (bit-reproducible) + the epilogue of the main kernel.
@@ -423,15 +353,41 @@ extern "C" int lcm_set_workspace(void* ptr, int64_t bytes) {
     g_ws_bytes[dev] = ptr ? bytes : 0;
     return LCM_OK;
 }
+void lcm_launch_splitk_reduce(const IgemmParams& p, hipStream_t s) {
+    const long long n4 = (long long)p.M * (p.N / 4);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, p);
+}
+
+float* lcm_splitk_workspace(long long* bytes) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 16) { *bytes = 0; return nullptr; }
+    *bytes = g_ws[dev] ? g_ws_bytes[dev] : 0;
+    return g_ws[dev];
+}
+
 // Tile + split-K selection.  Candidates in order of per-FLOP efficiency (128x128, 128x64, 64x128, 64x64);
 // split-K (deterministic slab reduce) tops a launch up to >= ~1.5 workgroups per CU when the output alone
 // has too few tiles (deep-K, small-M layers: the low-resolution UNet levels at batch 1).
 struct TilePick { int bm, bn, splits; };
 static int g_target_wgs = 384, g_max_splits = 16, g_min_wgs = 256;
-static int g_variant = 2;      // 0: register-staged double buffer (v1); 2/3/4: LDS-DMA pipeline with that many stages
+static int g_variant = -1;     // -1: auto (1 stage when >= 4 workgroups per CU are available, else 2); 0: register-staged
+                               // double buffer (v1); 1/2/3/4: LDS-DMA pipeline with that many stages
+
+void lcm_tuning(int* target_wgs, int* max_splits, int* min_wgs) {
+    *target_wgs = g_target_wgs; *max_splits = g_max_splits; *min_wgs = g_min_wgs;
+}
+
+static int g_conv_impl = 1;    // 1: LDS-halo conv (conv_halo.hip) for stride-1 3x3; 0: row-gather igemm everywhere
+
+extern "C" int lcm_set_conv_impl(int impl) {
+    if (impl != 0 && impl != 1) { lcm_set_error("conv_impl: %d", impl); return LCM_EINVAL; }
+    g_conv_impl = impl;
+    return LCM_OK;
+}
 
 extern "C" int lcm_set_kernel_variant(int variant) {
-    if (variant != 0 && variant != 2 && variant != 3 && variant != 4) { lcm_set_error("kernel_variant: %d", variant); return LCM_EINVAL; }
+    if (variant < -1 || variant > 4) { lcm_set_error("kernel_variant: %d", variant); return LCM_EINVAL; }
     g_variant = variant;
     return LCM_OK;
 }
@@ -494,6 +450,7 @@ static int launch_cfg(IgemmParams& p, int batch, int splits, hipStream_t s) {
     p.splits = splits;
     dim3 grid(p.mtiles * p.ntiles, splits, batch);
     int variant = g_variant;
+    if (variant < 0) variant = ((long long)grid.x * grid.y * grid.z >= 1024) ? 1 : 2;
     if (variant == 4 && BM + BN > 192) variant = 3;      // 4 x 32 KiB stages only for the small tiles
     if (variant == 0) {
         const int smem = 2 * (BM + BN) * 128;
@@ -504,6 +461,8 @@ static int launch_cfg(IgemmParams& p, int batch, int splits, hipStream_t s) {
             attr_set = true;
         }
         hipLaunchKernelGGL((igemm_kernel<BM, BN, MODE>), grid, dim3(256), smem, s, p);
+    } else if (variant == 1) {
+        launch_v2<BM, BN, MODE, 1>(p, grid, s);
     } else if (variant == 2) {
         launch_v2<BM, BN, MODE, 2>(p, grid, s);
     } else if (variant == 3) {
@@ -562,6 +521,47 @@ extern "C" int lcm_gemm_f16(const void* A, int lda, const void* A2, int lda2, in
     return launch_igemm<0>(p, batch, (hipStream_t)stream);
 }
 
+struct HaloParams {
+    IgemmParams g;
+    int C1;
+    const float* gn_scale;
+    const float* gn_shift;
+    int silu;
+    int H, W;
+    int tiles_y, tiles_x;
+};
+int lcm_conv_halo_launch(HaloParams& hp, int B, hipStream_t s);
+
+extern "C" int lcm_conv3x3_gn_f16(const void* in, int C1, const void* in2, int C2, const void* gn_scale,
+                                  const void* gn_shift, int silu, const void* W, const void* bias, const void* rowadd,
+                                  int ld_rowadd, const void* res, void* out, int B, int Hin, int Win, int Cout, int ups,
+                                  void* stream) {
+    LCM_REQUIRE(in && W && out, "conv3x3_gn: null pointer");
+    if (!in2) C2 = 0;
+    const int Cin = C1 + C2;
+    LCM_REQUIRE(B > 0 && Hin > 0 && Win > 0, "conv3x3_gn: bad shape");
+    LCM_REQUIRE(C1 % 64 == 0 && C2 % 64 == 0 && Cout % 64 == 0, "conv3x3_gn: C1=%d C2=%d Cout=%d must be multiples of 64", C1, C2, Cout);
+    LCM_REQUIRE((gn_scale == nullptr) == (gn_shift == nullptr), "conv3x3_gn: scale/shift must come together");
+    if (rowadd) LCM_REQUIRE(ld_rowadd % 4 == 0, "conv3x3_gn: ld_rowadd misaligned");
+    HaloParams hp = {};
+    IgemmParams& p = hp.g;
+    p.A = (const half_t*)in; p.A2 = (const half_t*)in2; p.W = (const half_t*)W; p.bias = (const half_t*)bias;
+    p.rowadd = (const half_t*)rowadd; p.res = (const half_t*)res; p.out = (half_t*)out;
+    p.Hin = Hin; p.Win = Win; p.Cin = Cin; p.stride = 1; p.ups = ups;
+    hp.H = ups ? 2 * Hin : Hin; hp.W = ups ? 2 * Win : Win;
+    p.Hout = hp.H; p.Wout = hp.W;
+    p.M = B * hp.H * hp.W; p.N = Cout; p.K = 9 * Cin;
+    p.ldo = Cout; p.ldr = Cout; p.ld_rowadd = ld_rowadd; p.rows_per_batch = hp.H * hp.W;
+    p.epi = 0; p.out_scale = 1.0f; p.splits = 1;
+    hp.C1 = C1; hp.gn_scale = (const float*)gn_scale; hp.gn_shift = (const float*)gn_shift; hp.silu = silu;
+    if (lcm_conv_halo_launch(hp, B, (hipStream_t)stream) != 0) {
+        lcm_set_error("conv3x3_gn: no tile configuration for B=%d %dx%d Cin=%d Cout=%d", B, hp.H, hp.W, Cin, Cout);
+        return LCM_EINVAL;
+    }
+    LCM_CHECK_LAUNCH("conv_halo");
+    return LCM_OK;
+}
+
 extern "C" int lcm_conv3x3_f16(const void* in, const void* W, const void* bias,
                                const void* rowadd, int ld_rowadd, const void* res, void* out,
                                int B, int Hin, int Win, int Cin, int Cout, int stride, int ups, void* stream) {
@@ -571,6 +571,9 @@ extern "C" int lcm_conv3x3_f16(const void* in, const void* W, const void* bias,
     LCM_REQUIRE(stride == 1 || stride == 2, "conv3x3: stride %d", stride);
     LCM_REQUIRE(!(ups && stride != 1), "conv3x3: upsample needs stride 1");
     if (rowadd) LCM_REQUIRE(ld_rowadd % 4 == 0, "conv3x3: ld_rowadd misaligned");
+    if (stride == 1 && g_conv_impl == 1)
+        return lcm_conv3x3_gn_f16(in, Cin, nullptr, 0, nullptr, nullptr, 0, W, bias, rowadd, ld_rowadd, res, out, B, Hin, Win,
+                                  Cout, ups, stream);
     const int Hl = ups ? 2 * Hin : Hin, Wl = ups ? 2 * Win : Win;
     IgemmParams p = {};
     p.A = (const half_t*)in; p.W = (const half_t*)W; p.bias = (const half_t*)bias;

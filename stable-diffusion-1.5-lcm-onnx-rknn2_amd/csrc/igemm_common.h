@@ -1,0 +1,96 @@
+// Shared pieces of the MFMA contraction kernels (igemm.hip, conv_halo.hip): parameter block, XCD-aware
+// tile remap, and the common epilogue (split-K slab store | bias + row add + scale + residual | GEGLU).
+#pragma once
+#include "common.h"
+
+struct IgemmParams {
+    const half_t* A;
+    const half_t* A2;
+    const half_t* W;
+    const half_t* bias;
+    const half_t* rowadd;
+    const half_t* res;
+    half_t* out;
+    int M, N, K;
+    int lda, lda2, K1;
+    int ldo, ldr, ld_rowadd, rows_per_batch;
+    int epi;
+    float out_scale;
+    long long strideA, strideW, strideO;
+    // conv
+    int Hin, Win, Cin, Hout, Wout, stride, ups;
+    int mtiles, ntiles;
+    int splits;          // split-K: blockIdx.y owns k-tiles [y*nk/splits, (y+1)*nk/splits); partials -> ws
+    float* ws;           // fp32 [splits][M][N]
+};
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    // contiguous chunk of tiles per XCD (blocks are dealt round-robin over the 8 XCDs)
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+template <int BM, int BN>
+__device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f4 (&acc)[BN / 32][BM / 32], const int (&m_of)[BM / 32],
+                                               int n_wave, int fq, int z) {
+    // m_of[b]: global output row of this lane in m-tile b, or -1 (outside the problem); n_wave: first channel of
+    // this wave's BN/2-wide slice.
+    constexpr int TM = BM / 32, TN = BN / 32;
+    if (p.splits > 1) {   // split-K: raw fp32 partial slab, epilogue runs in splitk_reduce_kernel
+        float* __restrict__ wsb = p.ws + (long long)blockIdx.y * p.M * p.N;
+#pragma unroll
+        for (int b = 0; b < TM; ++b) {
+            const int m = m_of[b];
+            if (m < 0) continue;
+#pragma unroll
+            for (int a = 0; a < TN; ++a) {
+                const int n = n_wave + a * 16 + fq * 4;
+                *reinterpret_cast<f4*>(wsb + (long long)m * p.N + n) = acc[a][b];
+            }
+        }
+        return;
+    }
+
+    // ---- epilogue: lane holds out[m = ..+frow][n = ..+fq*4 .. +3] ----
+    half_t* __restrict__ outb = p.out + z * p.strideO;
+#pragma unroll
+    for (int b = 0; b < TM; ++b) {
+        const int m = m_of[b];
+        if (m < 0) continue;
+        const half_t* radd = p.rowadd ? p.rowadd + (long long)(m / p.rows_per_batch) * p.ld_rowadd : nullptr;
+        if (p.epi == 0) {
+#pragma unroll
+            for (int a = 0; a < TN; ++a) {
+                const int n = n_wave + a * 16 + fq * 4;
+                f4 v = acc[a][b];
+                if (p.bias) { h4 t = *reinterpret_cast<const h4*>(p.bias + n);
+                    v[0] += (float)t[0]; v[1] += (float)t[1]; v[2] += (float)t[2]; v[3] += (float)t[3]; }
+                if (radd) { h4 t = *reinterpret_cast<const h4*>(radd + n);
+                    v[0] += (float)t[0]; v[1] += (float)t[1]; v[2] += (float)t[2]; v[3] += (float)t[3]; }
+                v[0] *= p.out_scale; v[1] *= p.out_scale; v[2] *= p.out_scale; v[3] *= p.out_scale;
+                if (p.res) { h4 t = *reinterpret_cast<const h4*>(p.res + (long long)m * p.ldr + n);
+                    v[0] += (float)t[0]; v[1] += (float)t[1]; v[2] += (float)t[2]; v[3] += (float)t[3]; }
+                h4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                *reinterpret_cast<h4*>(outb + (long long)m * p.ldo + n) = o;
+            }
+        } else {  // GEGLU: even n-tile = value rows, odd n-tile = gate rows (16-row interleave)
+#pragma unroll
+            for (int a = 0; a < TN; a += 2) {
+                const int n = n_wave + a * 16 + fq * 4;      // packed row of the value
+                f4 x = acc[a][b], g = acc[a + 1][b];
+                if (p.bias) {
+                    h4 tx = *reinterpret_cast<const h4*>(p.bias + n);
+                    h4 tg = *reinterpret_cast<const h4*>(p.bias + n + 16);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { x[j] += (float)tx[j]; g[j] += (float)tg[j]; }
+                }
+                h4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (half_t)(x[j] * gelu_erf_f(g[j]));
+                const int nout = ((n_wave + a * 16) >> 1) + fq * 4;
+                *reinterpret_cast<h4*>(outb + (long long)m * p.ldo + nout) = o;
+            }
+        }
+    }
+}
+

@@ -125,6 +125,32 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict_
 }
 
 // rows of HW per stats workgroup: aim for ~1024 workgroups per launch, at least 16 rows each
+// Same reduction, but emits the GroupNorm affine folded per (image, channel):
+//   scale[b][c] = rstd * gamma[c],  shift[b][c] = beta[c] - mean * rstd * gamma[c]
+// consumed by the fused conv loader (conv_halo.hip) so the normalised tensor is never materialised.
+__global__ __launch_bounds__(64) void gn_finalize_affine_kernel(const float* __restrict__ part, const half_t* __restrict__ gamma,
+                                                                const half_t* __restrict__ beta, float* __restrict__ scale,
+                                                                float* __restrict__ shift, int nchunk, int groups, int C,
+                                                                float inv_count, float eps) {
+    const int bg = blockIdx.x;
+    const int b = bg / groups, g = bg - b * groups, lane = threadIdx.x;
+    float s = 0.f, q = 0.f;
+    for (int c = lane; c < nchunk; c += 64) {
+        const float* p = part + (((long long)b * nchunk + c) * groups + g) * 2;
+        s += p[0]; q += p[1];
+    }
+    s = wave_sum(s); q = wave_sum(q);
+    const float mean = s * inv_count;
+    const float rstd = rsqrtf(fmaxf(q * inv_count - mean * mean, 0.f) + eps);
+    const int cpg = C / groups;
+    for (int j = lane; j < cpg; j += 64) {
+        const int c = g * cpg + j;
+        const float a = rstd * (float)gamma[c];
+        scale[(long long)b * C + c] = a;
+        shift[(long long)b * C + c] = (float)beta[c] - mean * a;
+    }
+}
+
 static inline int gn_rows(int B, int HW) {
     long long r = ((long long)B * HW + 1023) / 1024;
     if (r < 16) r = 16;
@@ -164,6 +190,27 @@ extern "C" int lcm_groupnorm_f16(const void* x, int C1, const void* x2, int C2, 
                        (const half_t*)x, C1, (const half_t*)x2, C2, (const half_t*)gamma, (const half_t*)beta, stats,
                        (half_t*)out, HW, groups, silu, rows_per_wg);
     LCM_CHECK_LAUNCH("gn_apply");
+    return LCM_OK;
+}
+
+extern "C" int lcm_groupnorm_affine_f16(const void* x, int C1, const void* x2, int C2, const void* gamma,
+                                        const void* beta, void* scale_out, void* shift_out, int B, int HW, int groups,
+                                        float eps, void* ws, void* stream) {
+    LCM_REQUIRE(x && gamma && beta && scale_out && shift_out && ws, "groupnorm_affine: null pointer");
+    if (!x2) C2 = 0;
+    const int C = C1 + C2;
+    LCM_REQUIRE(B > 0 && HW > 0 && groups > 0 && groups <= 64, "groupnorm_affine: bad shape B=%d HW=%d G=%d", B, HW, groups);
+    LCM_REQUIRE(C1 % 8 == 0 && C2 % 8 == 0 && C % groups == 0 && C <= GN_MAXC, "groupnorm_affine: bad channels %d+%d", C1, C2);
+    hipStream_t s = (hipStream_t)stream;
+    const int nchunk = gn_nchunk(B, HW);
+    float* part = (float*)ws;
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, B), dim3(256), 0, s, (const half_t*)x, C1, (const half_t*)x2, C2,
+                       part, HW, groups, nchunk, gn_rows(B, HW));
+    LCM_CHECK_LAUNCH("gn_stats");
+    hipLaunchKernelGGL(gn_finalize_affine_kernel, dim3(B * groups), dim3(64), 0, s, part, (const half_t*)gamma,
+                       (const half_t*)beta, (float*)scale_out, (float*)shift_out, nchunk, groups, C,
+                       1.0f / ((float)HW * (float)(C / groups)), eps);
+    LCM_CHECK_LAUNCH("gn_finalize_affine");
     return LCM_OK;
 }
 

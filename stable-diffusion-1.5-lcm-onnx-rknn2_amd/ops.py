@@ -79,6 +79,33 @@ def conv3x3(x, w, out, B, H, W, Cin, Cout, *, bias=None, rowadd=None, res=None, 
     return out
 
 
+def conv3x3_gn(x, w, out, B, H, W, C1, Cout, *, x2=None, C2=0, gn_scale=None, gn_shift=None, silu=True, bias=None,
+               rowadd=None, res=None, ups=0):
+    """Fused [GroupNorm-apply (+SiLU)] -> conv3x3 (stride 1) over the channel concat [x | x2]."""
+    L = _lib.load()
+    Cin = C1 + (C2 if x2 is not None else 0)
+    Ho, Wo = (2 * H, 2 * W) if ups else (H, W)
+    Mo = B * Ho * Wo
+    with _Timed("conv3x3", "halo", 2.0 * Mo * Cout * 9 * Cin, 2.0 * (B * H * W * Cin + 9 * Cin * Cout + Mo * Cout)):
+        rc = L.lcm_conv3x3_gn_f16(_p(x), C1, _p(x2), C2 if x2 is not None else 0, _p(gn_scale), _p(gn_shift),
+                                  1 if silu else 0, _p(w), _p(bias), _p(rowadd),
+                                  rowadd.stride(0) if rowadd is not None else 0, _p(res), _p(out), B, H, W, Cout, ups,
+                                  _stream())
+    _lib.check(rc, "lcm_conv3x3_gn_f16")
+    return out
+
+
+def groupnorm_affine(x, gamma, beta, scale, shift, B, HW, C1, ws, *, x2=None, C2=0, groups=32, eps=1e-5):
+    L = _lib.load()
+    rc = L.lcm_groupnorm_affine_f16(_p(x), C1, _p(x2), C2 if x2 is not None else 0, _p(gamma), _p(beta), _p(scale),
+                                    _p(shift), B, HW, groups, float(eps), _p(ws), _stream())
+    _lib.check(rc, "lcm_groupnorm_affine_f16")
+
+
+def set_conv_impl(impl):
+    _lib.check(_lib.load().lcm_set_conv_impl(int(impl)), "lcm_set_conv_impl")
+
+
 def conv3x3_c4(lat_f32, w, out, B, H, W, Cout, *, bias=None, pre_w=None, pre_b=None, in_scale=1.0):
     L = _lib.load()
     rc = L.lcm_conv3x3_c4_f32in(_p(lat_f32), _p(pre_w), _p(pre_b), float(in_scale), _p(w), _p(bias), _p(out),

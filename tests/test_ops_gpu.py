@@ -110,6 +110,63 @@ def test_conv3x3(B, H, W, Cin, Cout, stride, ups):
     close(from_nhwc(out, B, Ho, Wo), ref, what="conv3x3")
 
 
+@pytest.mark.parametrize("B,H,W,C1,C2,Cout,ups,silu,splitk", [
+    (2, 16, 16, 320, 0, 320, 0, True, False), (1, 64, 64, 320, 0, 320, 0, True, False),
+    (1, 16, 16, 1280, 640, 1280, 0, True, True), (2, 8, 8, 1280, 1280, 1280, 0, True, True),
+    (1, 24, 40, 128, 0, 128, 0, True, False), (1, 12, 20, 256, 0, 128, 1, False, False),
+    (1, 1, 1, 1280, 0, 1280, 0, True, True), (3, 5, 7, 64, 64, 64, 0, True, False), (1, 32, 32, 640, 320, 640, 0, True, True),
+    (1, 128, 128, 128, 0, 128, 0, True, False)])
+def test_conv3x3_gn_fused(B, H, W, C1, C2, Cout, ups, silu, splitk):
+    """GroupNorm(32)+SiLU -> conv3x3 over the skip concat, against F.group_norm / F.silu / F.conv2d."""
+    C = C1 + C2
+    x1 = rnd(B, C1, H, W, seed=1) * 1.5 + 0.3
+    x2 = rnd(B, C2, H, W, seed=2) * 0.7 - 0.5 if C2 else None
+    xc = torch.cat([x1, x2], 1) if C2 else x1
+    gamma, beta = (1 + 0.1 * rnd(C, seed=3).float()).half(), rnd(C, seed=4, scale=0.1)
+    w = rnd(Cout, C, 3, 3, seed=5, scale=(9 * C) ** -0.5)
+    b, radd = rnd(Cout, seed=6), rnd(B, Cout, seed=7)
+    h = F.group_norm(xc.float(), 32, gamma.float(), beta.float(), 1e-5)
+    if silu:
+        h = F.silu(h)
+    if ups:
+        h = F.interpolate(h, scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(h, w.float(), b.float(), padding=1) + radd.float()[:, :, None, None]
+    Ho, Wo = ref.shape[2:]
+    res = rnd(B, Cout, Ho, Wo, seed=8)
+    ref = ref + res.float()
+    d1 = to_nhwc(x1).to(DEV)
+    d2 = to_nhwc(x2).to(DEV) if C2 else None
+    ws = torch.empty(ops.groupnorm_ws_bytes(B, H * W, C) // 4 + 16, dtype=torch.float32, device=DEV)
+    scale = torch.empty(B, C, dtype=torch.float32, device=DEV)
+    shift = torch.empty(B, C, dtype=torch.float32, device=DEV)
+    ops.groupnorm_affine(d1, gamma.to(DEV), beta.to(DEV), scale, shift, B, H * W, C1, ws, x2=d2, C2=C2)
+    out = torch.empty(B * Ho * Wo, Cout, dtype=torch.float16, device=DEV)
+    skws = torch.empty(16 << 20, dtype=torch.float32, device=DEV)
+    ops.set_workspace(skws if splitk else None)
+    try:
+        ops.conv3x3_gn(d1, pack3x3(w).to(DEV), out, B, H, W, C1, Cout, x2=d2, C2=C2, gn_scale=scale, gn_shift=shift,
+                       silu=silu, bias=b.to(DEV), rowadd=radd.to(DEV), res=to_nhwc(res).to(DEV), ups=ups)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_workspace(None)
+    close(from_nhwc(out, B, Ho, Wo), ref, rtol=6e-3, what="conv3x3_gn")
+
+
+def test_conv_halo_matches_row_gather_igemm():
+    """The two 3x3 implementations agree to fp32 summation-order noise on a plain conv (border + m-tail)."""
+    B, H, W, Cin, Cout = 2, 20, 28, 192, 128
+    x = to_nhwc(rnd(B, Cin, H, W, seed=1)).to(DEV)
+    w = pack3x3(rnd(Cout, Cin, 3, 3, seed=2, scale=(9 * Cin) ** -0.5)).to(DEV)
+    outs = []
+    for impl in (0, 1):
+        ops.set_conv_impl(impl)
+        o = torch.empty(B * H * W, Cout, dtype=torch.float16, device=DEV)
+        ops.conv3x3(x, w, o, B, H, W, Cin, Cout)
+        outs.append(o.float().cpu())
+    ops.set_conv_impl(1)
+    assert (outs[0] - outs[1]).abs().max() < 4e-3
+
+
 @pytest.mark.parametrize("B,H,Cin,Cout", [(1, 8, 1280, 1280), (1, 16, 640, 1280), (1, 32, 640, 640), (1, 64, 320, 320),
                                          (2, 8, 2560, 1280)])
 def test_conv3x3_splitk(B, H, Cin, Cout):
@@ -136,13 +193,14 @@ def test_conv3x3_splitk(B, H, Cin, Cout):
     assert torch.equal(o1, o2)
 
 
-@pytest.mark.parametrize("variant", [2, 3, 4])
+@pytest.mark.parametrize("variant", [0, 1, 3, 4])
 def test_contraction_kernel_variants(variant):
     """The LDS-DMA pipeline variants must reproduce the register-staged kernel bit for bit
     (same MFMA contraction order), on conv (borders, upsample, stride 2, m-tail) and split-source gemm."""
     cases = [(2, 12, 20, 128, 192, 1, 0), (1, 9, 7, 64, 64, 2, 0), (1, 6, 10, 192, 128, 1, 1), (1, 64, 64, 320, 320, 1, 0),
              (1, 8, 8, 1280, 1280, 1, 0)]
     ws = torch.empty(16 << 20, dtype=torch.float32, device=DEV)
+    ops.set_conv_impl(0)
     try:
         for (B, H, W, Cin, Cout, stride, ups) in cases:
             x = to_nhwc(rnd(B, Cin, H, W, seed=1)).to(DEV)
@@ -150,7 +208,7 @@ def test_contraction_kernel_variants(variant):
             b = rnd(Cout, seed=3).to(DEV)
             Ho, Wo = ((2 * H, 2 * W) if ups else ((H + 1) // 2, (W + 1) // 2) if stride == 2 else (H, W))
             outs = []
-            for v in (0, variant):
+            for v in (2, variant):
                 ops.set_kernel_variant(v)
                 ops.set_workspace(ws)
                 o = torch.empty(B * Ho * Wo, Cout, dtype=torch.float16, device=DEV)
@@ -162,7 +220,7 @@ def test_contraction_kernel_variants(variant):
         a1, a2 = rnd(M, K1, seed=1).to(DEV), rnd(M, K2, seed=2).to(DEV)
         w = rnd(N, K1 + K2, seed=3, scale=0.03).to(DEV)
         outs = []
-        for v in (0, variant):
+        for v in (2, variant):
             ops.set_kernel_variant(v)
             o = torch.empty(M, N, dtype=torch.float16, device=DEV)
             ops.gemm(a1, w, o, a2=a2)
@@ -170,7 +228,8 @@ def test_contraction_kernel_variants(variant):
         torch.cuda.synchronize()
         assert torch.equal(outs[0], outs[1])
     finally:
-        ops.set_kernel_variant(2)      # library default
+        ops.set_kernel_variant(-1)     # library default (auto)
+        ops.set_conv_impl(1)
         ops.set_workspace(None)
 
 

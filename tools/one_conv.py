@@ -1,0 +1,16 @@
+#!/usr/bin/env python3
+"""Run one conv3x3 shape a few times (target for rocprofv3 --pmc passes)."""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sdlcm_amd  # noqa
+from sdlcm_amd import ops
+B, H, Cin, Cout = (int(v) for v in sys.argv[1:5])
+variant = int(sys.argv[5]) if len(sys.argv) > 5 else 2
+ops.set_kernel_variant(variant)
+x = torch.randn(B * H * H, Cin, device="cuda", dtype=torch.float16)
+w = torch.randn(Cout, 9 * Cin, device="cuda", dtype=torch.float16)
+o = torch.empty(B * H * H, Cout, device="cuda", dtype=torch.float16)
+for _ in range(5):
+    ops.conv3x3(x, w, o, B, H, H, Cin, Cout)
+torch.cuda.synchronize()

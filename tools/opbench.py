@@ -67,7 +67,7 @@ def variant_sweep():
         o = torch.empty(B * H * H, Cout, device=DEV, dtype=torch.float16)
         fl = 2.0 * B * H * H * Cout * 9 * Cin
         line = f"conv B{B} {H}x{H} {Cin}->{Cout}:"
-        for v in (0, 2, 3, 4):
+        for v in (0, 2, 1):
             ops.set_kernel_variant(v)
             t = timeit(lambda: ops.conv3x3(x, w, o, B, H, H, Cin, Cout))
             line += f"  v{v} {t * 1e6:7.1f}us {fl / t / 1e12:6.0f}TF"
@@ -76,17 +76,43 @@ def variant_sweep():
         a, w = rnd(M, K), rnd(N, K)
         o = torch.empty(M, N, device=DEV, dtype=torch.float16)
         line = f"gemm M{M} N{N} K{K}:"
-        for v in (0, 2, 3, 4):
+        for v in (0, 2, 1):
             ops.set_kernel_variant(v)
             t = timeit(lambda: ops.gemm(a, w, o))
             line += f"  v{v} {t * 1e6:7.1f}us {2.0 * M * N * K / t / 1e12:6.0f}TF"
         print(line)
-    ops.set_kernel_variant(2)
+    ops.set_kernel_variant(-1)
+    ops.set_workspace(None)
+
+
+def halo_sweep():
+    ws = torch.empty(64 << 18, dtype=torch.float32, device=DEV)
+    ops.set_workspace(ws)
+    convs = ((1, 64, 320, 320), (1, 32, 640, 640), (1, 16, 1280, 1280), (1, 8, 1280, 1280), (8, 64, 320, 320), (8, 32, 640, 640),
+             (8, 16, 1280, 1280), (8, 8, 1280, 1280), (8, 64, 960, 320), (8, 16, 2560, 1280), (1, 128, 512, 512), (1, 256, 256, 256),
+             (1, 512, 128, 128), (8, 128, 512, 512), (8, 256, 256, 256))
+    for (B, H, Cin, Cout) in convs:
+        x, w = rnd(B * H * H, Cin), rnd(Cout, 9 * Cin)
+        o = torch.empty(B * H * H, Cout, device=DEV, dtype=torch.float16)
+        sc = torch.ones(B, Cin, device=DEV)
+        sh = torch.zeros(B, Cin, device=DEV)
+        fl = 2.0 * B * H * H * Cout * 9 * Cin
+        line = f"conv B{B} {H}x{H} {Cin}->{Cout}:"
+        for name, impl in (("igemm", 0), ("halo", 1)):
+            ops.set_conv_impl(impl)
+            t = timeit(lambda: ops.conv3x3(x, w, o, B, H, H, Cin, Cout))
+            line += f"  {name} {t * 1e6:7.1f}us {fl / t / 1e12:6.0f}TF"
+        t = timeit(lambda: ops.conv3x3_gn(x, w, o, B, H, H, Cin, Cout, gn_scale=sc, gn_shift=sh, silu=True))
+        line += f"  halo+gn {t * 1e6:7.1f}us {fl / t / 1e12:6.0f}TF"
+        print(line)
+    ops.set_conv_impl(1)
     ops.set_workspace(None)
 
 
 def main():
     print("device", torch.cuda.get_device_name(0))
+    if len(sys.argv) > 1 and sys.argv[1] == "halo":
+        return halo_sweep()
     if len(sys.argv) > 1 and sys.argv[1] == "splitk":
         return splitk_sweep()
     if len(sys.argv) > 1 and sys.argv[1] == "variants":
