@@ -38,7 +38,21 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* __restrict_
             float s[8], q[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
-            for (int r = r0 + rl; r < r1; r += nrl) {
+            int r = r0 + rl;
+            // 4 independent 16-byte loads in flight per thread (HBM-bound: keep the memory pipe full)
+            for (; r + 3 * nrl < r1; r += 4 * nrl) {
+                h8 v0 = load_cat8(x, C1, x2, C2, rowbase + r, cc * 8);
+                h8 v1 = load_cat8(x, C1, x2, C2, rowbase + r + nrl, cc * 8);
+                h8 v2 = load_cat8(x, C1, x2, C2, rowbase + r + 2 * nrl, cc * 8);
+                h8 v3 = load_cat8(x, C1, x2, C2, rowbase + r + 3 * nrl, cc * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float a = (float)v0[j], b = (float)v1[j], c = (float)v2[j], d = (float)v3[j];
+                    s[j] += (a + b) + (c + d);
+                    q[j] += (a * a + b * b) + (c * c + d * d);
+                }
+            }
+            for (; r < r1; r += nrl) {
                 h8 v = load_cat8(x, C1, x2, C2, rowbase + r, cc * 8);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { float f = (float)v[j]; s[j] += f; q[j] += f * f; }
@@ -76,55 +90,54 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* __restrict_
     }
 }
 
-__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ part, float* __restrict__ stats,
-                                                         int nchunk, int groups, float inv_count, float eps) {
-    const int bg = blockIdx.x;              // b*groups + g
-    const int b = bg / groups, g = bg - b * groups, lane = threadIdx.x;
-    float s = 0.f, q = 0.f;
-    for (int c = lane; c < nchunk; c += 64) {
-        const float* p = part + (((long long)b * nchunk + c) * groups + g) * 2;
-        s += p[0]; q += p[1];
-    }
-    s = wave_sum(s); q = wave_sum(q);
-    if (lane == 0) {
-        const float mean = s * inv_count;
-        const float var = fmaxf(q * inv_count - mean * mean, 0.f);
-        stats[bg * 2] = mean;
-        stats[bg * 2 + 1] = rsqrtf(var + eps);
-    }
-}
-
 __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict__ x, int C1,
                                                        const half_t* __restrict__ x2, int C2,
-                                                       const half_t* __restrict__ gamma, const half_t* __restrict__ beta,
-                                                       const float* __restrict__ stats, half_t* __restrict__ out,
-                                                       int HW, int groups, int silu, int rows_per_wg) {
-    __shared__ float st[128];
-    const int C = C1 + C2, ncc = C >> 3, cpg = C / groups;
+                                                       const float* __restrict__ scale, const float* __restrict__ shift,
+                                                       half_t* __restrict__ out, int HW, int silu, int rows_per_wg) {
+    // y = act(x * scale[b][c] + shift[b][c]); a thread keeps one 8-channel chunk and walks rows, so its affine
+    // coefficients live in registers and the loop is load / 8 fma / store.
+    const int C = C1 + C2, ncc = C >> 3;
     const int b = blockIdx.y, tid = threadIdx.x;
-    if (tid < groups * 2) st[tid] = stats[b * groups * 2 + tid];
-    __syncthreads();
     const int r0 = blockIdx.x * rows_per_wg, r1 = min(HW, r0 + rows_per_wg);
     const long long rowbase = (long long)b * HW;
-    const int total = (r1 - r0) * ncc;
-    for (int i = tid; i < total; i += 256) {
-        const int r = r0 + i / ncc, cc = i % ncc, c = cc * 8;
-        h8 v = load_cat8(x, C1, x2, C2, rowbase + r, c);
-        h8 gm = *reinterpret_cast<const h8*>(gamma + c);
-        h8 bt = *reinterpret_cast<const h8*>(beta + c);
-        h8 o;
+    const int nrl = ncc <= 256 ? 256 / ncc : 1;
+    for (int cc0 = 0; cc0 < ncc; cc0 += 256) {
+        int rl, cc;
+        if (ncc <= 256) { rl = tid / ncc; cc = tid - rl * ncc; if (rl >= nrl) return; }
+        else { rl = 0; cc = cc0 + tid; if (cc >= ncc) continue; }
+        const int c = cc * 8;
+        float sc[8], sh[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int g = (c + j) / cpg;
-            float f = ((float)v[j] - st[g * 2]) * st[g * 2 + 1] * (float)gm[j] + (float)bt[j];
-            if (silu) f = silu_f(f);
-            o[j] = (half_t)f;
+        for (int j = 0; j < 8; ++j) { sc[j] = scale[(long long)b * C + c + j]; sh[j] = shift[(long long)b * C + c + j]; }
+        int r = r0 + rl;
+        for (; r + nrl < r1; r += 2 * nrl) {
+            h8 v0 = load_cat8(x, C1, x2, C2, rowbase + r, c);
+            h8 v1 = load_cat8(x, C1, x2, C2, rowbase + r + nrl, c);
+            h8 o0, o1;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float f0 = (float)v0[j] * sc[j] + sh[j], f1 = (float)v1[j] * sc[j] + sh[j];
+                if (silu) { f0 = silu_f(f0); f1 = silu_f(f1); }
+                o0[j] = (half_t)f0; o1[j] = (half_t)f1;
+            }
+            *reinterpret_cast<h8*>(out + (rowbase + r) * C + c) = o0;
+            *reinterpret_cast<h8*>(out + (rowbase + r + nrl) * C + c) = o1;
         }
-        *reinterpret_cast<h8*>(out + (rowbase + r) * C + c) = o;
+        for (; r < r1; r += nrl) {
+            h8 v = load_cat8(x, C1, x2, C2, rowbase + r, c);
+            h8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float f = (float)v[j] * sc[j] + sh[j];
+                if (silu) f = silu_f(f);
+                o[j] = (half_t)f;
+            }
+            *reinterpret_cast<h8*>(out + (rowbase + r) * C + c) = o;
+        }
+        if (ncc <= 256) break;
     }
 }
 
-// rows of HW per stats workgroup: aim for ~1024 workgroups per launch, at least 16 rows each
 // Same reduction, but emits the GroupNorm affine folded per (image, channel):
 //   scale[b][c] = rstd * gamma[c],  shift[b][c] = beta[c] - mean * rstd * gamma[c]
 // consumed by the fused conv loader (conv_halo.hip) so the normalised tensor is never materialised.
@@ -159,9 +172,13 @@ static inline int gn_rows(int B, int HW) {
 }
 static inline int gn_nchunk(int B, int HW) { const int r = gn_rows(B, HW); return (HW + r - 1) / r; }
 
+extern "C" int lcm_groupnorm_affine_f16(const void* x, int C1, const void* x2, int C2, const void* gamma,
+                                        const void* beta, void* scale_out, void* shift_out, int B, int HW, int groups,
+                                        float eps, void* ws, void* stream);
+
 extern "C" int64_t lcm_groupnorm_ws_bytes(int B, int HW, int C, int groups) {
-    (void)C;
-    return ((int64_t)B * gn_nchunk(B, HW) * groups * 2 + (int64_t)B * groups * 2) * 4;
+    // chunk partials + the [B][C] scale / shift tables used by lcm_groupnorm_f16
+    return ((int64_t)B * gn_nchunk(B, HW) * groups * 2 + 2 * (int64_t)B * C) * 4 + 64;
 }
 
 extern "C" int lcm_groupnorm_f16(const void* x, int C1, const void* x2, int C2, const void* gamma,
@@ -170,25 +187,20 @@ extern "C" int lcm_groupnorm_f16(const void* x, int C1, const void* x2, int C2, 
     LCM_REQUIRE(x && gamma && beta && out && ws, "groupnorm: null pointer");
     if (!x2) C2 = 0;
     const int C = C1 + C2;
-    LCM_REQUIRE(B > 0 && HW > 0 && groups > 0 && groups <= 64, "groupnorm: bad shape B=%d HW=%d G=%d", B, HW, groups);
-    LCM_REQUIRE(C1 % 8 == 0 && C2 % 8 == 0 && C % groups == 0 && C <= GN_MAXC, "groupnorm: bad channels %d+%d", C1, C2);
-    hipStream_t s = (hipStream_t)stream;
-    const int nchunk = gn_nchunk(B, HW);
     float* part = (float*)ws;
-    float* stats = part + (long long)B * nchunk * groups * 2;
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, B), dim3(256), 0, s, (const half_t*)x, C1, (const half_t*)x2, C2,
-                       part, HW, groups, nchunk, gn_rows(B, HW));
-    LCM_CHECK_LAUNCH("gn_stats");
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * groups), dim3(64), 0, s, part, stats, nchunk, groups,
-                       1.0f / ((float)HW * (float)(C / groups)), eps);
-    LCM_CHECK_LAUNCH("gn_finalize");
-    // 1..8 vectors per thread: aim for >= 1024 workgroups on small tensors
-    long long vec_per_wg = (long long)B * HW * (C >> 3) / 1024;
-    vec_per_wg = vec_per_wg < 256 ? 256 : (vec_per_wg > 2048 ? 2048 : vec_per_wg);
-    const int rows_per_wg = max(1, (int)(vec_per_wg / (C >> 3)));
-    hipLaunchKernelGGL(gn_apply_kernel, dim3((HW + rows_per_wg - 1) / rows_per_wg, B), dim3(256), 0, s,
-                       (const half_t*)x, C1, (const half_t*)x2, C2, (const half_t*)gamma, (const half_t*)beta, stats,
-                       (half_t*)out, HW, groups, silu, rows_per_wg);
+    float* scale = part + (((long long)B * gn_nchunk(B, HW) * groups * 2 + 3) & ~3ll);
+    float* shift = scale + (long long)B * C;
+    int rc = lcm_groupnorm_affine_f16(x, C1, x2, C2, gamma, beta, scale, shift, B, HW, groups, eps, ws, stream);
+    if (rc) return rc;
+    // rows per workgroup: >= 1024 workgroups on small tensors, up to ~16 rows per row-lane on large ones
+    const int ncc = C >> 3;
+    const int nrl = ncc <= 256 ? 256 / ncc : 1;
+    long long rows = ((long long)B * HW + 1023) / 1024;
+    if (rows < nrl) rows = nrl;
+    if (rows > 16ll * nrl) rows = 16ll * nrl;
+    const int rows_per_wg = (int)rows;
+    hipLaunchKernelGGL(gn_apply_kernel, dim3((HW + rows_per_wg - 1) / rows_per_wg, B), dim3(256), 0, (hipStream_t)stream,
+                       (const half_t*)x, C1, (const half_t*)x2, C2, scale, shift, (half_t*)out, HW, silu, rows_per_wg);
     LCM_CHECK_LAUNCH("gn_apply");
     return LCM_OK;
 }

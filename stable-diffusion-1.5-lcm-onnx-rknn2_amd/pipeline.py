@@ -88,6 +88,10 @@ class LcmHipPipeline:
         self._splitk_ws = torch.empty(int(os.environ.get("LCM_SPLITK_WS_MB", "64")) << 18, dtype=torch.float32,
                                       device=self.device)
         ops.set_workspace(self._splitk_ws)
+        if "LCM_CONV_IMPL" in os.environ:            # A/B switches for kernel work
+            ops.set_conv_impl(int(os.environ["LCM_CONV_IMPL"]))
+        if "LCM_KERNEL_VARIANT" in os.environ:
+            ops.set_kernel_variant(int(os.environ["LCM_KERNEL_VARIANT"]))
 
     # ------------------------------------------------------------------------------------------
     def _enqueue(self, P: _Plan, guidance: float, want_float=False, taps=None):
