@@ -14,6 +14,7 @@
 //     ds_read_b64_tr_b16 (hardware transpose) per fragment; row strides are chosen conflict-free.
 //   * K/V tiles are register-staged one tile ahead (loads issued before the MFMAs of the current tile).
 #include "common.h"
+#include <type_traits>
 
 struct AttnParams {
     const half_t* Q; const half_t* K; const half_t* V; half_t* O;
@@ -32,6 +33,11 @@ struct AttnCfg {
     static constexpr int NCH = D / 8;                 // 16-byte chunks per row
     static constexpr int NLD = (64 * NCH + 255) / 256;  // staged chunks per thread per tensor
     static constexpr int LDS_BYTES = 64 * KS + 64 * VS;
+    // Row sums on the matrix core: when V has a padding column (DV > D) it is set to 1.0, so row D of
+    // O^T = V^T P^T is sum_k P[q][k] (accumulated in fp32, rescaled together with O).  It lands in lanes 0-31,
+    // register ONES_REG of d-block ONES_DB.  Needs (D % 32) % 8 < 4, true for 40 and 80.
+    static constexpr bool ONES = (DV > D) && ((D % 32) % 8 < 4);
+    static constexpr int ONES_DB = D / 32, ONES_REG = 4 * ((D % 32) >> 3) + ((D % 32) & 3);
 };
 
 template <int D>
@@ -53,6 +59,10 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
 
     // zero LDS once: pad columns (d >= D) must read as 0
     for (int i = tid * 16; i < C::LDS_BYTES; i += 256 * 16) *reinterpret_cast<f4*>(smem + i) = (f4){0.f, 0.f, 0.f, 0.f};
+    if (C::ONES) {
+        __syncthreads();
+        if (tid < 64) *reinterpret_cast<half_t*>(Vs + tid * C::VS + D * 2) = (half_t)1.0f;   // never overwritten: tiles fill cols < D
+    }
 
     // Q fragments (B operand): lane holds Q[qrow][16ks + 8hh + j]
     h8 qf[C::DK / 16];
@@ -106,7 +116,8 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
     const int k_addr = l31 * C::KS + 16 * hh;                                  // + kb*32*KS + ks*32
     const int v_addr = (4 * hh + ((lane & 15) >> 2)) * C::VS + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
 
-    for (int t = 0; t < ntiles; ++t) {
+    auto tile_body = [&](int t, auto ragged_tag) {
+        constexpr bool RAGGED = decltype(ragged_tag)::value;
         __syncthreads();          // everyone done reading the previous tile (and the zero fill)
         store_tile();
         __syncthreads();
@@ -116,16 +127,15 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
         f16v sacc[2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
+            const f16v zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < C::DK / 16; ++ks) {
                 h8 kf = *reinterpret_cast<const h8*>(Ks + k_addr + kb * 32 * C::KS + ks * 32);
-                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], sacc[kb], 0, 0, 0);
+                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], ks == 0 ? zero : sacc[kb], 0, 0, 0);
             }
         }
         // ---- online softmax (per-lane query column) ----
-        if (t * 64 + 64 > p.Sk) {
+        if (RAGGED) {                  // last, ragged tile only (separate code path: no per-tile select cost)
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -141,23 +151,28 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
             for (int r = 0; r < 16; ++r) mt = fmaxf(mt, sacc[kb][r]);
         mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
         const float m_new = fmaxf(m_run, mt * p.sc);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
+        // The running max settles after the first few tiles; when no lane's max moved, alpha == 1 exactly and the
+        // O rescale (an AGPR read-modify-write of the whole accumulator) is skipped -- wave-uniform branch.
+        if (!__all(m_new == m_run)) {
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < C::DV / 32; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+            m_run = m_new;
+        }
         float psum = 0.f;
         h8 pf[2][2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pv = __builtin_amdgcn_exp2f(sacc[kb][r] * p.sc - m_new);
-                psum += pv;
+                const float pv = __builtin_amdgcn_exp2f(sacc[kb][r] * p.sc - m_run);
+                if (!C::ONES) psum += pv;
                 pf[kb][r >> 3][r & 7] = (half_t)pv;
             }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int i = 0; i < C::DV / 32; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+        if (!C::ONES) l_run += psum;
 
         // ---- O^T += V^T P^T ----
 #pragma unroll
@@ -175,10 +190,17 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
                     oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kb][s], oacc[db], 0, 0, 0);
                 }
         }
+    };
+    const bool ragged = (p.Sk & 63) != 0;
+    for (int t = 0; t < ntiles; ++t) {
+        if (ragged && t == ntiles - 1) tile_body(t, std::true_type{});
+        else tile_body(t, std::false_type{});
     }
 
     // ---- epilogue: O[q][d] = O^T[d][q] / l ----
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    float l_tot;
+    if (C::ONES) l_tot = __shfl(oacc[C::ONES_DB][C::ONES_REG], l31, 64);    // row D of O^T lives in lanes 0-31
+    else l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
     if (qrow < p.Sq) {
         half_t* orow = p.O + ((long long)b * p.Sq + qrow) * p.ldo + head * D;
