@@ -56,6 +56,13 @@ int lcm_set_workspace(void* ptr, int64_t bytes);
  * maximum number of K splits, and the workgroup count below which a larger tile is passed over. */
 int lcm_set_tuning(int target_wgs, int max_splits, int min_wgs);
 
+/* Per-shape launch plans, normally written by the host-side autotuner (stable-diffusion-1.5-lcm-onnx-rknn2_amd/
+ * autotune.py): kind 0 = lcm_gemm_f16 (aux = batch), 1 = row-gather conv (aux = 1), 2 = LDS-halo conv
+ * (aux = (W_out << 1) | has_gn).  bm/bn in {64,128}; splits = K splits (needs the workspace); variant as below
+ * (-1 = auto).  A plan only changes tile/split selection, never results beyond fp32 summation order. */
+int lcm_plan_set(int kind, int M, int N, int K, int aux, int bm, int bn, int splits, int variant);
+int lcm_plan_clear(void);
+
 /* contraction kernel variant: 0 = register-staged double buffer, 2/3/4 = LDS-DMA pipeline with that many stages */
 int lcm_set_kernel_variant(int variant);
 

@@ -1,0 +1,82 @@
+"""Per-shape launch autotuner for the MFMA contraction kernels (gemm / conv3x3).
+
+The sampler touches ~80 distinct (M, N, K) contraction shapes per (batch, size) plan.  Tile shape, split-K
+factor and pipeline variant are pure launch parameters (results change only in fp32 summation order), and the
+best choice depends on how many workgroups a shape yields on 256 CUs.  At plan-build time every distinct shape
+is replayed on its real buffers under each candidate configuration, timed with HIP events on the launch stream,
+and the winner is written to the library's plan table (``lcm_plan_set``).  ~0.5 s per plan, once.
+
+Disable with LCM_AUTOTUNE=0 (the built-in heuristics of csrc/igemm.hip then apply).
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+
+from . import ops
+
+
+def _candidates(key, meta, ws_bytes):
+    kind, M, N, K, aux = key
+    nk = K // 64
+    tiles = []
+    for bm in (128, 64):
+        for bn in (128, 64):
+            if N % bn:
+                continue
+            if meta["halo"]:
+                tw = 16 if (meta["W"] % 16 == 0 or meta["W"] > 16) else 8
+                if tw == 8 and bm == 128:
+                    continue
+            elif bm == 128 and M < 128:
+                continue
+            tiles.append((bm, bn))
+    out = []
+    for bm, bn in tiles:
+        ntile = -(-M // bm) * (N // bn) * (aux if kind == 0 else 1)
+        units = (K // 576) if meta["halo"] else nk            # halo conv splits over 64-channel chunks
+        splits = [1]
+        if meta["splittable"]:
+            for s in (2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 24, 32):
+                if s <= units and ntile * s <= 4096 and s * M * N * 4 <= ws_bytes and (meta["halo"] or s <= nk // 2):
+                    splits.append(s)
+        for s in splits:
+            variants = (-1,) if meta["halo"] else (1, 2)
+            for v in variants:
+                out.append((bm, bn, s, v))
+    return out
+
+
+def _time(fn, reps):
+    fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def autotune(records, ws_bytes, reps=None, verbose=False):
+    """records: list of (key, meta, replay) from ops.RECORD.  Returns {key: (bm, bn, splits, variant, ms)}."""
+    reps = reps or int(os.environ.get("LCM_AUTOTUNE_REPS", "6"))
+    seen, chosen = {}, {}
+    for key, meta, fn in records:
+        seen.setdefault(key, (meta, fn))
+    for key, (meta, fn) in seen.items():
+        best = None
+        for (bm, bn, s, v) in _candidates(key, meta, ws_bytes):
+            ops.plan_set(key[0], key[1], key[2], key[3], key[4], bm, bn, s, v)
+            # hold the stream briefly so the timed launches run back to back (host enqueue is slower than tiny kernels)
+            ops.debug_spin(150)
+            ms = _time(fn, reps)
+            if best is None or ms < best[4]:
+                best = (bm, bn, s, v, ms)
+        ops.plan_set(key[0], key[1], key[2], key[3], key[4], *best[:4])
+        chosen[key] = best
+        if verbose:
+            print(f"[autotune] kind{key[0]} M{key[1]} N{key[2]} K{key[3]} aux{key[4]} -> {best[0]}x{best[1]} "
+                  f"splits {best[2]} variant {best[3]} {best[4] * 1e3:.1f}us")
+    return chosen

@@ -196,6 +196,7 @@ __global__ __launch_bounds__(256, 3) void conv_halo_kernel(HaloParams hp) {
 extern void lcm_launch_splitk_reduce(const IgemmParams& p, hipStream_t s);
 extern float* lcm_splitk_workspace(long long* bytes);
 extern void lcm_tuning(int* target_wgs, int* max_splits, int* min_wgs);
+extern bool lcm_plan_get(int kind, int M, int N, int K, int aux, int* bm, int* bn, int* splits, int* variant);
 
 template <int TH, int TW, int BN, int XFORM>
 static void launch_halo(HaloParams& hp, hipStream_t s) {
@@ -240,6 +241,14 @@ int lcm_conv_halo_launch(HaloParams& hp, int B, hipStream_t s) {
         const long long wgs = tiles * sp;
         if (wgs >= min_wgs) { bm = cbm; bn = cbn; splits = sp; break; }
         if (wgs > best) { best = wgs; bm = cbm; bn = cbn; splits = sp; }
+    }
+    {   // autotuned plan for this shape, if any (kind 2; aux = (W << 1) | xform)
+        int pbm, pbn, psp, pv;
+        if (lcm_plan_get(2, p.M, p.N, p.K, (hp.W << 1) | (hp.gn_scale ? 1 : 0), &pbm, &pbn, &psp, &pv) && p.N % pbn == 0 &&
+            !(TW == 8 && pbm == 128)) {
+            if (psp > 1 && (!p.ws || (long long)psp * p.M * p.N * 4 > ws_bytes || psp > nchunks)) psp = 1;
+            bm = pbm; bn = pbn; splits = psp;
+        }
     }
     if (!bm) return 1;
     const int th = bm / TW;

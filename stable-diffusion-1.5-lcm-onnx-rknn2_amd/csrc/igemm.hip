@@ -366,6 +366,38 @@ float* lcm_splitk_workspace(long long* bytes) {
     return g_ws[dev];
 }
 
+// ---- per-shape launch plans (filled by the host-side autotuner; heuristics below are the fallback) ----
+#include <map>
+#include <mutex>
+#include <tuple>
+struct PlanVal { int bm, bn, splits, variant; };
+static std::map<std::tuple<int, int, int, int, int>, PlanVal> g_plans;
+static std::mutex g_plans_mu;
+
+extern "C" int lcm_plan_set(int kind, int M, int N, int K, int aux, int bm, int bn, int splits, int variant) {
+    if (!((bm == 128 || bm == 64) && (bn == 128 || bn == 64) && splits >= 1 && splits <= 64 && variant >= -1 && variant <= 4)) {
+        lcm_set_error("plan_set: bad plan %dx%d splits %d variant %d", bm, bn, splits, variant);
+        return LCM_EINVAL;
+    }
+    std::lock_guard<std::mutex> lk(g_plans_mu);
+    g_plans[std::make_tuple(kind, M, N, K, aux)] = PlanVal{bm, bn, splits, variant};
+    return LCM_OK;
+}
+
+extern "C" int lcm_plan_clear(void) {
+    std::lock_guard<std::mutex> lk(g_plans_mu);
+    g_plans.clear();
+    return LCM_OK;
+}
+
+bool lcm_plan_get(int kind, int M, int N, int K, int aux, int* bm, int* bn, int* splits, int* variant) {
+    std::lock_guard<std::mutex> lk(g_plans_mu);
+    auto it = g_plans.find(std::make_tuple(kind, M, N, K, aux));
+    if (it == g_plans.end()) return false;
+    *bm = it->second.bm; *bn = it->second.bn; *splits = it->second.splits; *variant = it->second.variant;
+    return true;
+}
+
 // Tile + split-K selection.  Candidates in order of per-FLOP efficiency (128x128, 128x64, 64x128, 64x64);
 // split-K (deterministic slab reduce) tops a launch up to >= ~1.5 workgroups per CU when the output alone
 // has too few tiles (deep-K, small-M layers: the low-resolution UNet levels at batch 1).
@@ -444,12 +476,12 @@ static int launch_v2(IgemmParams& p, dim3 grid, hipStream_t s) {
 }
 
 template <int BM, int BN, int MODE>
-static int launch_cfg(IgemmParams& p, int batch, int splits, hipStream_t s) {
+static int launch_cfg(IgemmParams& p, int batch, int splits, int plan_variant, hipStream_t s) {
     p.mtiles = (p.M + BM - 1) / BM;
     p.ntiles = p.N / BN;
     p.splits = splits;
     dim3 grid(p.mtiles * p.ntiles, splits, batch);
-    int variant = g_variant;
+    int variant = g_variant >= 0 ? g_variant : plan_variant;
     if (variant < 0) variant = ((long long)grid.x * grid.y * grid.z >= 1024) ? 1 : 2;
     if (variant == 4 && BM + BN > 192) variant = 3;      // 4 x 32 KiB stages only for the small tiles
     if (variant == 0) {
@@ -485,13 +517,19 @@ static int launch_igemm(IgemmParams& p, int batch, hipStream_t s) {
     (void)hipGetDevice(&dev);
     p.ws = (dev >= 0 && dev < 16) ? g_ws[dev] : nullptr;
     const long long wsb = p.ws ? g_ws_bytes[dev] : 0;
-    const TilePick t = pick_tile(p.M, p.N, p.K, batch, wsb, p.ws != nullptr && p.epi == 0);
+    TilePick t = pick_tile(p.M, p.N, p.K, batch, wsb, p.ws != nullptr && p.epi == 0);
+    int variant = -1, pbm, pbn, psp, pv;
+    if (lcm_plan_get(MODE, p.M, p.N, p.K, batch, &pbm, &pbn, &psp, &pv) && p.N % pbn == 0) {
+        if (psp > 1 && (p.epi != 0 || batch != 1 || (long long)psp * p.M * p.N * 4 > wsb || psp > (p.K >> 6))) psp = 1;
+        t = {pbm, pbn, psp};
+        variant = pv;
+    }
     const int code = t.bm * 1000 + t.bn;
     switch (code) {
-        case 128128: return launch_cfg<128, 128, MODE>(p, batch, t.splits, s);
-        case 128064: return launch_cfg<128, 64, MODE>(p, batch, t.splits, s);
-        case 64128: return launch_cfg<64, 128, MODE>(p, batch, t.splits, s);
-        default: return launch_cfg<64, 64, MODE>(p, batch, t.splits, s);
+        case 128128: return launch_cfg<128, 128, MODE>(p, batch, t.splits, variant, s);
+        case 128064: return launch_cfg<128, 64, MODE>(p, batch, t.splits, variant, s);
+        case 64128: return launch_cfg<64, 128, MODE>(p, batch, t.splits, variant, s);
+        default: return launch_cfg<64, 64, MODE>(p, batch, t.splits, variant, s);
     }
 }
 

@@ -55,6 +55,8 @@ _SIGS = {
     "lcm_set_tuning": [_i, _i, _i],
     "lcm_set_kernel_variant": [_i],
     "lcm_set_conv_impl": [_i],
+    "lcm_plan_set": [_i] * 9,
+    "lcm_plan_clear": [],
     "lcm_conv3x3_gn_f16": [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "lcm_groupnorm_affine_f16": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp],
     "lcm_device_info": [_i, C.c_char_p, _i, C.POINTER(_i), C.POINTER(C.c_uint64)],

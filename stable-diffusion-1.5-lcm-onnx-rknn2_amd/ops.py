@@ -42,6 +42,18 @@ class _Timed:
         return False
 
 
+# Autotuner hook: when RECORD is a list, every contraction launch appends (plan key, replay closure).
+RECORD = None
+
+
+def plan_set(kind, M, N, K, aux, bm, bn, splits, variant=-1):
+    _lib.check(_lib.load().lcm_plan_set(kind, M, N, K, aux, bm, bn, splits, variant), "lcm_plan_set")
+
+
+def plan_clear():
+    _lib.check(_lib.load().lcm_plan_clear(), "lcm_plan_clear")
+
+
 def tile_config(M, N, batch=1):
     c = _lib.load().lcm_gemm_tile_config(int(M), int(N), int(batch))
     return f"{c // 1000}x{c % 1000}"
@@ -57,6 +69,12 @@ def gemm(a, w, out, *, bias=None, res=None, rowadd=None, rows_per_batch=0, a2=No
     N = w.shape[0] if N is None else N
     lda = a.stride(-2) if lda is None else lda
     ldo = out.stride(-2) if ldo is None else ldo
+    if RECORD is not None:
+        kw = dict(bias=bias, res=res, rowadd=rowadd, rows_per_batch=rows_per_batch, a2=a2, epilogue=epilogue,
+                  out_scale=out_scale, M=M, N=N, K=K, lda=lda, ldo=ldo, batch=batch, strideA=strideA, strideW=strideW,
+                  strideO=strideO)
+        RECORD.append(((0, M, N, K, batch), dict(splittable=(epilogue == 0 and batch == 1), halo=False),
+                       lambda: gemm(a, w, out, **kw)))
     with _Timed("gemm", tile_config(M, N, batch) if PROFILE is not None else "", 2.0 * M * N * K * batch,
                 2.0 * batch * (M * K + N * K + M * N)):
         rc = L.lcm_gemm_f16(_p(a), lda, _p(a2), a2.stride(0) if a2 is not None else 0, K1, _p(w), _p(bias), _p(rowadd),
@@ -71,6 +89,10 @@ def conv3x3(x, w, out, B, H, W, Cin, Cout, *, bias=None, rowadd=None, res=None, 
     L = _lib.load()
     Ho, Wo = ((2 * H, 2 * W) if ups else ((H + 1) // 2, (W + 1) // 2) if stride == 2 else (H, W))
     Mo = B * Ho * Wo
+    if RECORD is not None:
+        kw = dict(bias=bias, rowadd=rowadd, res=res, stride=stride, ups=ups)
+        key = (1, Mo, Cout, 9 * Cin, 1) if stride == 2 else (2, Mo, Cout, 9 * Cin, (Wo << 1))
+        RECORD.append((key, dict(splittable=True, halo=stride == 1, W=Wo), lambda: conv3x3(x, w, out, B, H, W, Cin, Cout, **kw)))
     with _Timed("conv3x3", tile_config(Mo, Cout) if PROFILE is not None else "", 2.0 * Mo * Cout * 9 * Cin,
                 2.0 * (B * H * W * Cin + 9 * Cin * Cout + Mo * Cout)):
         rc = L.lcm_conv3x3_f16(_p(x), _p(w), _p(bias), _p(rowadd), rowadd.stride(0) if rowadd is not None else 0,
@@ -86,6 +108,10 @@ def conv3x3_gn(x, w, out, B, H, W, C1, Cout, *, x2=None, C2=0, gn_scale=None, gn
     Cin = C1 + (C2 if x2 is not None else 0)
     Ho, Wo = (2 * H, 2 * W) if ups else (H, W)
     Mo = B * Ho * Wo
+    if RECORD is not None:
+        kw = dict(x2=x2, C2=C2, gn_scale=gn_scale, gn_shift=gn_shift, silu=silu, bias=bias, rowadd=rowadd, res=res, ups=ups)
+        RECORD.append(((2, Mo, Cout, 9 * Cin, (Wo << 1) | (1 if gn_scale is not None else 0)),
+                       dict(splittable=True, halo=True, W=Wo), lambda: conv3x3_gn(x, w, out, B, H, W, C1, Cout, **kw)))
     with _Timed("conv3x3", "halo", 2.0 * Mo * Cout * 9 * Cin, 2.0 * (B * H * W * Cin + 9 * Cin * Cout + Mo * Cout)):
         rc = L.lcm_conv3x3_gn_f16(_p(x), C1, _p(x2), C2 if x2 is not None else 0, _p(gn_scale), _p(gn_shift),
                                   1 if silu else 0, _p(w), _p(bias), _p(rowadd),

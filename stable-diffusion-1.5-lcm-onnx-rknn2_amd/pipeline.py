@@ -83,6 +83,7 @@ class LcmHipPipeline:
         self.sched = schedule or LCMSchedule()
         self.use_graph = use_graph
         self._plans = {}
+        self._tuned_keys = set()
         self.stream = torch.cuda.Stream(device=self.device)
         # fp32 scratch for deterministic split-K of the deep-K / small-M layers (low-res UNet levels at batch 1)
         self._splitk_ws = torch.empty(int(os.environ.get("LCM_SPLITK_WS_MB", "64")) << 18, dtype=torch.float32,
@@ -128,6 +129,25 @@ class LcmHipPipeline:
             P = _Plan(self, B, h, w, steps, do_cfg)
             self._plans[key] = P
         return P
+
+    def tune(self, P: _Plan, verbose=False):
+        """Autotune the launch plan of every contraction shape this plan touches (once per shape per process)."""
+        if os.environ.get("LCM_AUTOTUNE", "1") == "0" or getattr(P, "tuned", False):
+            return
+        from . import autotune
+        with torch.cuda.stream(self.stream):
+            self._enqueue(P, 1.0)                    # allocate scratch, warm caches
+            ops.RECORD = []
+            try:
+                self._enqueue(P, 1.0)
+            finally:
+                recs, ops.RECORD = ops.RECORD, None
+            self.stream.synchronize()
+            todo = [r for r in recs if r[0] not in self._tuned_keys]
+            res = autotune.autotune(todo, self._splitk_ws.numel() * 4, verbose=verbose)
+            self._tuned_keys.update(res.keys())
+            self.stream.synchronize()
+        P.tuned = True
 
     def drop_plans(self):
         for P in self._plans.values():
@@ -182,6 +202,7 @@ class LcmHipPipeline:
                 final = self._enqueue(P, guidance_scale, want_float=want_float, taps=taps)
             else:
                 if P.graph is None:
+                    self.tune(P)
                     self._enqueue(P, guidance_scale)           # warm-up: allocates every scratch buffer
                     self.stream.synchronize()
                     g = ops.Graph()
