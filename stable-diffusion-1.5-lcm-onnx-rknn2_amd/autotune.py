@@ -42,7 +42,7 @@ def _candidates(key, meta, ws_bytes):
                 if s <= units and ntile * s <= 4096 and s * M * N * 4 <= ws_bytes and (meta["halo"] or s <= nk // 2):
                     splits.append(s)
         for s in splits:
-            variants = (-1,) if meta["halo"] else (1, 2)
+            variants = (-1,) if meta["halo"] else ((1, 2, 4) if bm + bn <= 128 else (1, 2))
             for v in variants:
                 out.append((bm, bn, s, v))
     return out

@@ -276,7 +276,9 @@ __global__ __launch_bounds__(256, S == 1 ? 4 : 2) void igemm2_kernel(IgemmParams
             wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
         } else {
-            if (S >= 4 && newer >= 2) wait_vmcnt<(S >= 4 ? 2 : 0) * LPT>();
+            if (S >= 6 && newer >= 4) wait_vmcnt<(S >= 6 ? 4 : 0) * LPT>();
+            else if (S >= 5 && newer >= 3) wait_vmcnt<(S >= 5 ? 3 : 0) * LPT>();
+            else if (S >= 4 && newer >= 2) wait_vmcnt<(S >= 4 ? 2 : 0) * LPT>();
             else if (S >= 3 && newer >= 1) wait_vmcnt<(S >= 3 ? 1 : 0) * LPT>();
             else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
@@ -419,7 +421,7 @@ extern "C" int lcm_set_conv_impl(int impl) {
 }
 
 extern "C" int lcm_set_kernel_variant(int variant) {
-    if (variant < -1 || variant > 4) { lcm_set_error("kernel_variant: %d", variant); return LCM_EINVAL; }
+    if (variant < -1 || variant > 6) { lcm_set_error("kernel_variant: %d", variant); return LCM_EINVAL; }
     g_variant = variant;
     return LCM_OK;
 }
@@ -482,7 +484,13 @@ static int launch_cfg(IgemmParams& p, int batch, int splits, int plan_variant, h
     p.splits = splits;
     dim3 grid(p.mtiles * p.ntiles, splits, batch);
     int variant = g_variant >= 0 ? g_variant : plan_variant;
-    if (variant < 0) variant = ((long long)grid.x * grid.y * grid.z >= 1024) ? 1 : 2;
+    if (variant == 5) variant = (BM + BN <= 128) ? 4 : -1;      // deep prefetch on the small tile only
+    if (variant == 6) variant = (BM + BN <= 128) ? 6 : -1;
+    if (variant < 0) {   // auto: enough workgroups for 4 per CU -> single buffer; small tile -> 4-stage prefetch (short-K,
+                         // latency-bound GEMMs); else double buffer
+        const long long wgs = (long long)grid.x * grid.y * grid.z;
+        variant = wgs >= 1024 ? 1 : ((BM + BN <= 128) ? 4 : 2);
+    }
     if (variant == 4 && BM + BN > 192) variant = 3;      // 4 x 32 KiB stages only for the small tiles
     if (variant == 0) {
         const int smem = 2 * (BM + BN) * 128;
@@ -499,6 +507,8 @@ static int launch_cfg(IgemmParams& p, int batch, int splits, int plan_variant, h
         launch_v2<BM, BN, MODE, 2>(p, grid, s);
     } else if (variant == 3) {
         launch_v2<BM, BN, MODE, 3>(p, grid, s);
+    } else if (variant == 6) {
+        if constexpr (BM + BN <= 128) launch_v2<BM, BN, MODE, 6>(p, grid, s);
     } else {
         launch_v2<BM, BN, MODE, 4>(p, grid, s);
     }
