@@ -45,7 +45,15 @@ int lcm_gemm_f16(const void* A, int lda, const void* A2, int lda2, int K1,
                  const void* W, const void* bias, const void* rowadd, int ld_rowadd, int rows_per_batch,
                  const void* res, int ldr, void* out, int ldo,
                  int M, int N, int K, int epilogue, float out_scale,
-                 int batch, int64_t strideA, int64_t strideW, int64_t strideO, void* stream);
+                 int batch, int64_t strideA, int64_t strideW, int64_t strideO,
+                 void* stats_out, int stats_hw, int* slabs_per_image, void* stream);
+/* Fused GroupNorm statistics (all three contraction entry points): stats_out != NULL asks the epilogue to also
+ * write, per half-tile (or split-K reduce slab), the per-channel (sum, sum of squares) of the fp16 values it
+ * stores: fp32 [B * slabs_per_image][N][2].  stats_hw = output rows per image (gemm only; the convs know it).
+ * *slabs_per_image returns how many slabs each image got; 0 means the launch could not produce them (tile would
+ * straddle two images, GEGLU/batched launch, N > 2048): use lcm_groupnorm_f16 on the output instead.
+ * Consumer: lcm_groupnorm_from_stats_f16.  Buffer size: 8 * N * (max(M / 16, 256) + 64) bytes always suffices
+ * (>= 32-row slabs from the tile epilogues incl. padding patches; <= max(M/32, 256) slabs from a split-K reduce). */
 
 /* Optional fp32 scratch for deterministic split-K (deep-K, small-M layers).  The caller owns the memory; it is
  * registered per current device and must outlive every later launch (graph replays included).  Without it the
@@ -76,7 +84,8 @@ int lcm_gemm_tile_config(int M, int N, int batch);
  */
 int lcm_conv3x3_f16(const void* in, const void* W, const void* bias,
                     const void* rowadd, int ld_rowadd, const void* res, void* out,
-                    int B, int Hin, int Win, int Cin, int Cout, int stride, int ups, void* stream);
+                    int B, int Hin, int Win, int Cin, int Cout, int stride, int ups,
+                    void* stats_out, int* slabs_per_image, void* stream);
 
 /* ---- fused GroupNorm(+SiLU) -> 3x3 convolution, stride 1 (ResnetBlock2D norm1->act->conv1, norm2->act->conv2) ----
  * LDS-halo implicit GEMM (csrc/conv_halo.hip).  Input = channel concat [in | in2] (in2 NULL: single source; fused
@@ -87,7 +96,8 @@ int lcm_conv3x3_f16(const void* in, const void* W, const void* bias,
  */
 int lcm_conv3x3_gn_f16(const void* in, int C1, const void* in2, int C2, const void* gn_scale, const void* gn_shift,
                        int silu, const void* W, const void* bias, const void* rowadd, int ld_rowadd, const void* res,
-                       void* out, int B, int Hin, int Win, int Cout, int ups, void* stream);
+                       void* out, int B, int Hin, int Win, int Cout, int ups, void* stats_out, int* slabs_per_image,
+                       void* stream);
 /* GroupNorm statistics folded into per-(image, channel) fp32 scale/shift tables [B][C1+C2] for the call above;
  * ws as for lcm_groupnorm_f16. */
 int lcm_groupnorm_affine_f16(const void* x, int C1, const void* x2, int C2, const void* gamma, const void* beta,
@@ -119,6 +129,13 @@ int lcm_conv3x3_smalln(const void* in, const void* W, const void* bias, void* ou
 int64_t lcm_groupnorm_ws_bytes(int B, int HW, int C, int groups);
 int lcm_groupnorm_f16(const void* x, int C1, const void* x2, int C2, const void* gamma, const void* beta,
                       void* out, int B, int HW, int groups, float eps, int silu, void* ws, void* stream);
+
+/* GroupNorm (+SiLU) of [x | x2] from producer-written statistics (see lcm_gemm_f16): stats1 = [B*P1][C1][2],
+ * stats2 = [B*P2][C2][2] (x2/stats2 NULL: single source).  ws: >= 8*B*(C1+C2) bytes.  No pass over the data for
+ * the statistics: one finalize launch (per image x group) + the apply launch. */
+int lcm_groupnorm_from_stats_f16(const void* x, int C1, const void* x2, int C2, const void* stats1, int P1,
+                                 const void* stats2, int P2, const void* gamma, const void* beta, void* out,
+                                 int B, int HW, int groups, float eps, int silu, void* ws, void* stream);
 
 /* ---- LayerNorm over the last dim (BasicTransformerBlock.norm1/2/3) ---- */
 int lcm_layernorm_f16(const void* x, const void* gamma, const void* beta, void* out, int M, int C, float eps,

@@ -39,7 +39,16 @@ void lcm_set_error(const char* fmt, ...);
 __device__ __forceinline__ float silu_f(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
 }
-__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// exact-GELU 0.5 x (1 + erf(x/sqrt2)) with erf from Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below the fp16
+// output rounding): one v_rcp + one v_exp + a degree-5 Horner instead of libm erff (~4x fewer VALU in the GEGLU epilogue)
+__device__ __forceinline__ float gelu_erf_f(float x) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float erf_abs = 1.0f - poly * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);
+    const float erfv = copysignf(erf_abs, x);
+    return 0.5f * x * (1.0f + erfv);
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -189,11 +189,12 @@ __global__ __launch_bounds__(256, 3) void conv_halo_kernel(HaloParams hp) {
         const int y = y0 + q / TW, x = x0 + q % TW;
         m_of[b] = (y < hp.H && x < hp.W) ? (bimg * hp.H + y) * hp.W + x : -1;
     }
-    igemm_epilogue<BM, BN>(p, acc, m_of, n_base + wn * (BN / 2), fq, 0);
+    igemm_epilogue<BM, BN>(p, acc, m_of, n_base + wn * (BN / 2), fq, 0, mt * 2 + wm);
 }
 
 // split-K combine kernel lives in igemm.hip
-extern void lcm_launch_splitk_reduce(const IgemmParams& p, hipStream_t s);
+extern void lcm_launch_splitk_reduce(IgemmParams& p, hipStream_t s);
+extern int lcm_reduce_rows(int M, int hw);
 extern float* lcm_splitk_workspace(long long* bytes);
 extern void lcm_tuning(int* target_wgs, int* max_splits, int* min_wgs);
 extern bool lcm_plan_get(int kind, int M, int N, int K, int aux, int* bm, int* bn, int* splits, int* variant);
@@ -210,7 +211,7 @@ static void launch_halo(HaloParams& hp, hipStream_t s) {
 }
 
 // returns 0 when launched, 1 when the shape is not handled here (caller falls back to the row-gather igemm)
-int lcm_conv_halo_launch(HaloParams& hp, int B, hipStream_t s) {
+int lcm_conv_halo_launch(HaloParams& hp, int B, hipStream_t s, int* slabs_per_image) {
     IgemmParams& p = hp.g;
     const int TW = (hp.W % 16 == 0 || hp.W > 16) ? 16 : 8;
     int target, max_splits, min_wgs;
@@ -254,6 +255,16 @@ int lcm_conv_halo_launch(HaloParams& hp, int B, hipStream_t s) {
     const int th = bm / TW;
     p.mtiles = B * ((hp.H + th - 1) / th) * ((hp.W + TW - 1) / TW);
     p.splits = splits;
+    if (p.stats) {   // fused GroupNorm statistics of the output
+        if (p.N > 2048) p.stats = nullptr;
+        else if (splits > 1) {
+            p.reduce_rows = lcm_reduce_rows(p.M, hp.H * hp.W);
+            if (slabs_per_image) *slabs_per_image = hp.H * hp.W / p.reduce_rows;
+        } else if (slabs_per_image) {
+            *slabs_per_image = 2 * (p.mtiles / B);      // one slab per (patch, wave row)
+        }
+    }
+    if (splits > 1 && p.reduce_rows <= 0) p.reduce_rows = lcm_reduce_rows(p.M, 0);
     const bool xf = hp.gn_scale != nullptr;
 #define HALO_CASE(TH_, TW_, BN_)                                                           \
     if (th == TH_ && TW == TW_ && bn == BN_) {                                             \

@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
         const int m = m_base + wm * (BM / 2) + b * 16 + frow;
         m_of[b] = m < p.M ? m : -1;
     }
-    igemm_epilogue<BM, BN>(p, acc, m_of, n_base + wn * (BN / 2), fq, z);
+    igemm_epilogue<BM, BN>(p, acc, m_of, n_base + wn * (BN / 2), fq, z, mt * 2 + wm);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -315,31 +315,67 @@ __global__ __launch_bounds__(256, S == 1 ? 4 : 2) void igemm2_kernel(IgemmParams
         const int m = m_base + wm * (BM / 2) + b * 16 + frow;
         m_of[b] = m < p.M ? m : -1;
     }
-    igemm_epilogue<BM, BN>(p, acc, m_of, n_base + wn * (BN / 2), fq, z);
+    igemm_epilogue<BM, BN>(p, acc, m_of, n_base + wn * (BN / 2), fq, z, mt * 2 + wm);
 }
 
-// Split-K combine: fixed-order sum of the fp32 slabs (bit-reproducible) + the epilogue of the main kernel.
+// Split-K combine: fixed-order sum of the fp32 slabs (bit-reproducible) + the epilogue of the main kernel, and
+// optionally the fused GroupNorm statistics of the result.  A workgroup owns p.reduce_rows consecutive rows; a thread
+// owns one 4-channel group and walks rows, so per-channel sums need only a fixed-order fold over the row lanes.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(IgemmParams p) {
-    const long long i4 = (long long)blockIdx.x * 256 + threadIdx.x;      // index of a 4-channel group
-    const int n4 = p.N >> 2;
-    if (i4 >= (long long)p.M * n4) return;
-    const int m = (int)(i4 / n4), n = (int)(i4 - (long long)m * n4) * 4;
+    __shared__ float red[2048 * 2];
+    const int n4 = p.N >> 2, tid = threadIdx.x;
+    const int r0 = blockIdx.x * p.reduce_rows, r1 = min(p.M, r0 + p.reduce_rows);
     const long long slab = (long long)p.M * p.N;
-    const float* src = p.ws + (long long)m * p.N + n;
-    f4 v = *reinterpret_cast<const f4*>(src);
-    for (int s = 1; s < p.splits; ++s) {
-        f4 t = *reinterpret_cast<const f4*>(src + s * slab);
-        v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
+    const bool small = n4 <= 256;
+    const int nrl = small ? 256 / n4 : 1;
+    const int rl = small ? tid / n4 : 0;
+    const bool do_stats = p.stats != nullptr;
+    for (int cg = small ? tid - rl * n4 : tid; cg < n4; cg += 256) {
+        const int n = cg * 4;
+        float ss[4] = {0.f, 0.f, 0.f, 0.f}, qq[4] = {0.f, 0.f, 0.f, 0.f};
+        if (rl < nrl) {
+            f4 bias4 = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) { h4 t = *reinterpret_cast<const h4*>(p.bias + n); bias4 = (f4){(float)t[0], (float)t[1], (float)t[2], (float)t[3]}; }
+            for (int m = r0 + rl; m < r1; m += nrl) {
+                const float* src = p.ws + (long long)m * p.N + n;
+                f4 v = *reinterpret_cast<const f4*>(src);
+                for (int s = 1; s < p.splits; ++s) {
+                    f4 t = *reinterpret_cast<const f4*>(src + s * slab);
+                    v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
+                }
+                v[0] += bias4[0]; v[1] += bias4[1]; v[2] += bias4[2]; v[3] += bias4[3];
+                if (p.rowadd) { h4 t = *reinterpret_cast<const h4*>(p.rowadd + (long long)(m / p.rows_per_batch) * p.ld_rowadd + n);
+                    v[0] += (float)t[0]; v[1] += (float)t[1]; v[2] += (float)t[2]; v[3] += (float)t[3]; }
+                v[0] *= p.out_scale; v[1] *= p.out_scale; v[2] *= p.out_scale; v[3] *= p.out_scale;
+                if (p.res) { h4 t = *reinterpret_cast<const h4*>(p.res + (long long)m * p.ldr + n);
+                    v[0] += (float)t[0]; v[1] += (float)t[1]; v[2] += (float)t[2]; v[3] += (float)t[3]; }
+                h4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                *reinterpret_cast<h4*>(p.out + (long long)m * p.ldo + n) = o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const float f = (float)o[j]; ss[j] += f; qq[j] += f * f; }
+            }
+        }
+        if (do_stats) {
+            if (!small) {       // one thread owns the channel group for the whole slab
+                float* dst = p.stats + ((long long)blockIdx.x * p.N + n) * 2;
+                *reinterpret_cast<f4*>(dst) = (f4){ss[0], qq[0], ss[1], qq[1]};
+                *reinterpret_cast<f4*>(dst + 4) = (f4){ss[2], qq[2], ss[3], qq[3]};
+            } else if (rl < nrl) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { red[((rl * p.N) + n + j) * 2] = ss[j]; red[((rl * p.N) + n + j) * 2 + 1] = qq[j]; }
+            }
+        }
+        if (small) break;
     }
-    if (p.bias) { h4 t = *reinterpret_cast<const h4*>(p.bias + n);
-        v[0] += (float)t[0]; v[1] += (float)t[1]; v[2] += (float)t[2]; v[3] += (float)t[3]; }
-    if (p.rowadd) { h4 t = *reinterpret_cast<const h4*>(p.rowadd + (long long)(m / p.rows_per_batch) * p.ld_rowadd + n);
-        v[0] += (float)t[0]; v[1] += (float)t[1]; v[2] += (float)t[2]; v[3] += (float)t[3]; }
-    v[0] *= p.out_scale; v[1] *= p.out_scale; v[2] *= p.out_scale; v[3] *= p.out_scale;
-    if (p.res) { h4 t = *reinterpret_cast<const h4*>(p.res + (long long)m * p.ldr + n);
-        v[0] += (float)t[0]; v[1] += (float)t[1]; v[2] += (float)t[2]; v[3] += (float)t[3]; }
-    h4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-    *reinterpret_cast<h4*>(p.out + (long long)m * p.ldo + n) = o;
+    if (do_stats && small) {
+        __syncthreads();
+        for (int c = tid; c < p.N; c += 256) {
+            float s = 0.f, q = 0.f;
+            for (int r = 0; r < nrl; ++r) { s += red[(r * p.N + c) * 2]; q += red[(r * p.N + c) * 2 + 1]; }
+            float* dst = p.stats + ((long long)blockIdx.x * p.N + c) * 2;
+            dst[0] = s; dst[1] = q;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -355,9 +391,17 @@ extern "C" int lcm_set_workspace(void* ptr, int64_t bytes) {
     g_ws_bytes[dev] = ptr ? bytes : 0;
     return LCM_OK;
 }
-void lcm_launch_splitk_reduce(const IgemmParams& p, hipStream_t s) {
-    const long long n4 = (long long)p.M * (p.N / 4);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, p);
+// rows per reduce workgroup: a power of two <= 32 that divides `hw` (so a slab never straddles two images when the
+// fused statistics are on) and leaves >= ~128 workgroups
+int lcm_reduce_rows(int M, int hw) {
+    int rs = 32;
+    while (rs > 1 && (M / rs < 128 || (hw > 0 && hw % rs))) rs >>= 1;
+    return rs;
+}
+
+void lcm_launch_splitk_reduce(IgemmParams& p, hipStream_t s) {
+    if (p.reduce_rows <= 0) p.reduce_rows = lcm_reduce_rows(p.M, 0);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((p.M + p.reduce_rows - 1) / p.reduce_rows)), dim3(256), 0, s, p);
 }
 
 float* lcm_splitk_workspace(long long* bytes) {
@@ -514,15 +558,17 @@ static int launch_cfg(IgemmParams& p, int batch, int splits, int plan_variant, h
     }
     LCM_CHECK_LAUNCH("igemm");
     if (splits > 1) {
-        const long long n4 = (long long)p.M * (p.N / 4);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, p);
+        lcm_launch_splitk_reduce(p, s);
         LCM_CHECK_LAUNCH("splitk_reduce");
     }
     return LCM_OK;
 }
 
+// Fused-statistics bookkeeping: `stats_hw` = rows per image of the output.  On return *slabs_per_image is the
+// number of [N][2] partial rows the launch wrote per image (0 = statistics not produced: the tile shape would
+// straddle images; the caller then runs the standalone statistics kernel).
 template <int MODE>
-static int launch_igemm(IgemmParams& p, int batch, hipStream_t s) {
+static int launch_igemm(IgemmParams& p, int batch, hipStream_t s, int stats_hw = 0, int* slabs_per_image = nullptr) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     p.ws = (dev >= 0 && dev < 16) ? g_ws[dev] : nullptr;
@@ -534,6 +580,20 @@ static int launch_igemm(IgemmParams& p, int batch, hipStream_t s) {
         t = {pbm, pbn, psp};
         variant = pv;
     }
+    if (slabs_per_image) *slabs_per_image = 0;
+    if (p.stats) {
+        bool ok = stats_hw > 0 && p.epi == 0 && batch == 1 && p.N <= 2048 && p.M % stats_hw == 0;
+        if (ok && t.splits > 1) {
+            p.reduce_rows = lcm_reduce_rows(p.M, stats_hw);
+            if (slabs_per_image) *slabs_per_image = stats_hw / p.reduce_rows;
+        } else if (ok) {
+            if (stats_hw % t.bm != 0 && t.bm == 128 && stats_hw % 64 == 0) t.bm = 64;     // keep tiles inside one image
+            ok = stats_hw % t.bm == 0;
+            if (ok && slabs_per_image) *slabs_per_image = stats_hw / (t.bm / 2);
+        }
+        if (!ok) p.stats = nullptr;
+    }
+    if (t.splits > 1 && p.reduce_rows <= 0) p.reduce_rows = lcm_reduce_rows(p.M, 0);
     const int code = t.bm * 1000 + t.bn;
     switch (code) {
         case 128128: return launch_cfg<128, 128, MODE>(p, batch, t.splits, variant, s);
@@ -547,7 +607,8 @@ extern "C" int lcm_gemm_f16(const void* A, int lda, const void* A2, int lda2, in
                             const void* W, const void* bias, const void* rowadd, int ld_rowadd, int rows_per_batch,
                             const void* res, int ldr, void* out, int ldo,
                             int M, int N, int K, int epilogue, float out_scale,
-                            int batch, int64_t strideA, int64_t strideW, int64_t strideO, void* stream) {
+                            int batch, int64_t strideA, int64_t strideW, int64_t strideO,
+                            void* stats_out, int stats_hw, int* slabs_per_image, void* stream) {
     LCM_REQUIRE(A && W && out, "gemm: null pointer");
     LCM_REQUIRE(M > 0 && N > 0 && K > 0 && batch > 0, "gemm: bad shape M=%d N=%d K=%d batch=%d", M, N, K, batch);
     LCM_REQUIRE(K % 64 == 0, "gemm: K=%d must be a multiple of 64", K);
@@ -566,7 +627,8 @@ extern "C" int lcm_gemm_f16(const void* A, int lda, const void* A2, int lda2, in
     p.ldo = ldo; p.ldr = ldr; p.ld_rowadd = ld_rowadd; p.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1;
     p.epi = epilogue; p.out_scale = out_scale;
     p.strideA = strideA; p.strideW = strideW; p.strideO = strideO;
-    return launch_igemm<0>(p, batch, (hipStream_t)stream);
+    p.stats = (float*)stats_out;
+    return launch_igemm<0>(p, batch, (hipStream_t)stream, stats_hw, slabs_per_image);
 }
 
 struct HaloParams {
@@ -578,12 +640,12 @@ struct HaloParams {
     int H, W;
     int tiles_y, tiles_x;
 };
-int lcm_conv_halo_launch(HaloParams& hp, int B, hipStream_t s);
+int lcm_conv_halo_launch(HaloParams& hp, int B, hipStream_t s, int* slabs_per_image);
 
 extern "C" int lcm_conv3x3_gn_f16(const void* in, int C1, const void* in2, int C2, const void* gn_scale,
                                   const void* gn_shift, int silu, const void* W, const void* bias, const void* rowadd,
                                   int ld_rowadd, const void* res, void* out, int B, int Hin, int Win, int Cout, int ups,
-                                  void* stream) {
+                                  void* stats_out, int* slabs_per_image, void* stream) {
     LCM_REQUIRE(in && W && out, "conv3x3_gn: null pointer");
     if (!in2) C2 = 0;
     const int Cin = C1 + C2;
@@ -602,7 +664,9 @@ extern "C" int lcm_conv3x3_gn_f16(const void* in, int C1, const void* in2, int C
     p.ldo = Cout; p.ldr = Cout; p.ld_rowadd = ld_rowadd; p.rows_per_batch = hp.H * hp.W;
     p.epi = 0; p.out_scale = 1.0f; p.splits = 1;
     hp.C1 = C1; hp.gn_scale = (const float*)gn_scale; hp.gn_shift = (const float*)gn_shift; hp.silu = silu;
-    if (lcm_conv_halo_launch(hp, B, (hipStream_t)stream) != 0) {
+    p.stats = (float*)stats_out;
+    if (slabs_per_image) *slabs_per_image = 0;
+    if (lcm_conv_halo_launch(hp, B, (hipStream_t)stream, slabs_per_image) != 0) {
         lcm_set_error("conv3x3_gn: no tile configuration for B=%d %dx%d Cin=%d Cout=%d", B, hp.H, hp.W, Cin, Cout);
         return LCM_EINVAL;
     }
@@ -612,7 +676,8 @@ extern "C" int lcm_conv3x3_gn_f16(const void* in, int C1, const void* in2, int C
 
 extern "C" int lcm_conv3x3_f16(const void* in, const void* W, const void* bias,
                                const void* rowadd, int ld_rowadd, const void* res, void* out,
-                               int B, int Hin, int Win, int Cin, int Cout, int stride, int ups, void* stream) {
+                               int B, int Hin, int Win, int Cin, int Cout, int stride, int ups,
+                               void* stats_out, int* slabs_per_image, void* stream) {
     LCM_REQUIRE(in && W && out, "conv3x3: null pointer");
     LCM_REQUIRE(B > 0 && Hin > 0 && Win > 0, "conv3x3: bad shape");
     LCM_REQUIRE(Cin % 64 == 0 && Cout % 64 == 0, "conv3x3: Cin=%d Cout=%d must be multiples of 64", Cin, Cout);
@@ -621,7 +686,7 @@ extern "C" int lcm_conv3x3_f16(const void* in, const void* W, const void* bias,
     if (rowadd) LCM_REQUIRE(ld_rowadd % 4 == 0, "conv3x3: ld_rowadd misaligned");
     if (stride == 1 && g_conv_impl == 1)
         return lcm_conv3x3_gn_f16(in, Cin, nullptr, 0, nullptr, nullptr, 0, W, bias, rowadd, ld_rowadd, res, out, B, Hin, Win,
-                                  Cout, ups, stream);
+                                  Cout, ups, stats_out, slabs_per_image, stream);
     const int Hl = ups ? 2 * Hin : Hin, Wl = ups ? 2 * Win : Win;
     IgemmParams p = {};
     p.A = (const half_t*)in; p.W = (const half_t*)W; p.bias = (const half_t*)bias;
@@ -631,5 +696,6 @@ extern "C" int lcm_conv3x3_f16(const void* in, const void* W, const void* bias,
     p.M = B * p.Hout * p.Wout; p.N = Cout; p.K = 9 * Cin;
     p.ldo = Cout; p.ldr = Cout; p.ld_rowadd = ld_rowadd; p.rows_per_batch = p.Hout * p.Wout;
     p.epi = 0; p.out_scale = 1.0f;
-    return launch_igemm<1>(p, 1, (hipStream_t)stream);
+    p.stats = (float*)stats_out;
+    return launch_igemm<1>(p, 1, (hipStream_t)stream, p.Hout * p.Wout, slabs_per_image);
 }

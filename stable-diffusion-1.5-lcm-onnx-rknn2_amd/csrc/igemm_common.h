@@ -22,6 +22,9 @@ struct IgemmParams {
     int mtiles, ntiles;
     int splits;          // split-K: blockIdx.y owns k-tiles [y*nk/splits, (y+1)*nk/splits); partials -> ws
     float* ws;           // fp32 [splits][M][N]
+    float* stats;        // optional fused GroupNorm statistics of the OUTPUT: [slab][N][2] = per-channel (sum, sum of
+                         // squares) of the fp16-rounded values each half-tile (or reduce slab) stores; null = off
+    int reduce_rows;     // rows per workgroup of splitk_reduce_kernel
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -32,7 +35,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 template <int BM, int BN>
 __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f4 (&acc)[BN / 32][BM / 32], const int (&m_of)[BM / 32],
-                                               int n_wave, int fq, int z) {
+                                               int n_wave, int fq, int z, int stats_slab = 0) {
     // m_of[b]: global output row of this lane in m-tile b, or -1 (outside the problem); n_wave: first channel of
     // this wave's BN/2-wide slice.
     constexpr int TM = BM / 32, TN = BN / 32;
@@ -53,6 +56,12 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f4 (&acc)[B
 
     // ---- epilogue: lane holds out[m = ..+frow][n = ..+fq*4 .. +3] ----
     half_t* __restrict__ outb = p.out + z * p.strideO;
+    const bool do_stats = p.stats != nullptr && p.epi == 0;
+    float ssum[TN][4], ssq[TN][4];
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { ssum[a][j] = 0.f; ssq[a][j] = 0.f; }
 #pragma unroll
     for (int b = 0; b < TM; ++b) {
         const int m = m_of[b];
@@ -72,6 +81,10 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f4 (&acc)[B
                     v[0] += (float)t[0]; v[1] += (float)t[1]; v[2] += (float)t[2]; v[3] += (float)t[3]; }
                 h4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
                 *reinterpret_cast<h4*>(outb + (long long)m * p.ldo + n) = o;
+                if (do_stats) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { const float f = (float)o[j]; ssum[a][j] += f; ssq[a][j] += f * f; }
+                }
             }
         } else {  // GEGLU: even n-tile = value rows, odd n-tile = gate rows (16-row interleave)
 #pragma unroll
@@ -89,6 +102,25 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f4 (&acc)[B
                 for (int j = 0; j < 4; ++j) o[j] = (half_t)(x[j] * gelu_erf_f(g[j]));
                 const int nout = ((n_wave + a * 16) >> 1) + fq * 4;
                 *reinterpret_cast<h4*>(outb + (long long)m * p.ldo + nout) = o;
+            }
+        }
+    }
+    if (do_stats) {   // fold the 16 pixel-lanes of each channel quad, then one lane per quad writes (sum, sumsq) x 4
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int a = 0; a < TN; ++a) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    ssum[a][j] += __shfl_xor(ssum[a][j], o, 64);
+                    ssq[a][j] += __shfl_xor(ssq[a][j], o, 64);
+                }
+            }
+            if ((lane & 15) == 0) {
+                float* dst = p.stats + ((long long)stats_slab * p.N + n_wave + a * 16 + fq * 4) * 2;
+                *reinterpret_cast<f4*>(dst) = (f4){ssum[a][0], ssq[a][0], ssum[a][1], ssq[a][1]};
+                *reinterpret_cast<f4*>(dst + 4) = (f4){ssum[a][2], ssq[a][2], ssum[a][3], ssq[a][3]};
             }
         }
     }

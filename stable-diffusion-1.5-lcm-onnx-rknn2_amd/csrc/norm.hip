@@ -164,6 +164,57 @@ __global__ __launch_bounds__(64) void gn_finalize_affine_kernel(const float* __r
     }
 }
 
+// GroupNorm affine from the per-channel partial statistics the producing contraction kernel wrote in its epilogue
+// (csrc/igemm_common.h): stats[(b*P + p)][C][2].  One workgroup per (image, group); the group's channels may span
+// both sources of a fused concat.  Fixed-order reduction (thread-sequential, then an LDS tree): deterministic.
+__global__ __launch_bounds__(256) void gn_finalize_from_stats_kernel(const float* __restrict__ st1, int P1, int C1,
+                                                                     const float* __restrict__ st2, int P2, int C2,
+                                                                     const half_t* __restrict__ gamma, const half_t* __restrict__ beta,
+                                                                     float* __restrict__ scale, float* __restrict__ shift,
+                                                                     int groups, float inv_count, float eps) {
+    __shared__ float rs[256], rq[256];
+    const int C = C1 + C2, cpg = C / groups;
+    const int bg = blockIdx.x, b = bg / groups, g = bg - b * groups, tid = threadIdx.x;
+    const int c_lo = g * cpg, c_hi = c_lo + cpg;
+    float s = 0.f, q = 0.f;
+    {   // source 1: channels [c_lo, min(c_hi, C1))
+        const int a = c_lo, e = min(c_hi, C1), w = e - a;
+        if (w > 0) {
+            const int total = P1 * w;
+            for (int i = tid; i < total; i += 256) {
+                const int pp = i / w, c = a + (i - pp * w);
+                const float* v = st1 + (((long long)b * P1 + pp) * C1 + c) * 2;
+                s += v[0]; q += v[1];
+            }
+        }
+    }
+    {   // source 2: channels [max(c_lo, C1), c_hi)
+        const int a = max(c_lo, C1), e = c_hi, w = e - a;
+        if (w > 0 && st2) {
+            const int total = P2 * w;
+            for (int i = tid; i < total; i += 256) {
+                const int pp = i / w, c = a + (i - pp * w) - C1;
+                const float* v = st2 + (((long long)b * P2 + pp) * C2 + c) * 2;
+                s += v[0]; q += v[1];
+            }
+        }
+    }
+    rs[tid] = s; rq[tid] = q;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) { rs[tid] += rs[tid + o]; rq[tid] += rq[tid + o]; }
+        __syncthreads();
+    }
+    const float mean = rs[0] * inv_count;
+    const float rstd = rsqrtf(fmaxf(rq[0] * inv_count - mean * mean, 0.f) + eps);
+    for (int j = tid; j < cpg; j += 256) {
+        const int c = c_lo + j;
+        const float a = rstd * (float)gamma[c];
+        scale[(long long)b * C + c] = a;
+        shift[(long long)b * C + c] = (float)beta[c] - mean * a;
+    }
+}
+
 static inline int gn_rows(int B, int HW) {
     long long r = ((long long)B * HW + 1023) / 1024;
     if (r < 16) r = 16;
@@ -175,6 +226,8 @@ static inline int gn_nchunk(int B, int HW) { const int r = gn_rows(B, HW); retur
 extern "C" int lcm_groupnorm_affine_f16(const void* x, int C1, const void* x2, int C2, const void* gamma,
                                         const void* beta, void* scale_out, void* shift_out, int B, int HW, int groups,
                                         float eps, void* ws, void* stream);
+static int launch_gn_apply(const void* x, int C1, const void* x2, int C2, const float* scale, const float* shift, void* out,
+                           int B, int HW, int silu, hipStream_t s);
 
 extern "C" int64_t lcm_groupnorm_ws_bytes(int B, int HW, int C, int groups) {
     // chunk partials + the [B][C] scale / shift tables used by lcm_groupnorm_f16
@@ -192,17 +245,7 @@ extern "C" int lcm_groupnorm_f16(const void* x, int C1, const void* x2, int C2, 
     float* shift = scale + (long long)B * C;
     int rc = lcm_groupnorm_affine_f16(x, C1, x2, C2, gamma, beta, scale, shift, B, HW, groups, eps, ws, stream);
     if (rc) return rc;
-    // rows per workgroup: >= 1024 workgroups on small tensors, up to ~16 rows per row-lane on large ones
-    const int ncc = C >> 3;
-    const int nrl = ncc <= 256 ? 256 / ncc : 1;
-    long long rows = ((long long)B * HW + 1023) / 1024;
-    if (rows < nrl) rows = nrl;
-    if (rows > 16ll * nrl) rows = 16ll * nrl;
-    const int rows_per_wg = (int)rows;
-    hipLaunchKernelGGL(gn_apply_kernel, dim3((HW + rows_per_wg - 1) / rows_per_wg, B), dim3(256), 0, (hipStream_t)stream,
-                       (const half_t*)x, C1, (const half_t*)x2, C2, scale, shift, (half_t*)out, HW, silu, rows_per_wg);
-    LCM_CHECK_LAUNCH("gn_apply");
-    return LCM_OK;
+    return launch_gn_apply(x, C1, x2, C2, scale, shift, out, B, HW, silu, (hipStream_t)stream);
 }
 
 extern "C" int lcm_groupnorm_affine_f16(const void* x, int C1, const void* x2, int C2, const void* gamma,
@@ -224,6 +267,39 @@ extern "C" int lcm_groupnorm_affine_f16(const void* x, int C1, const void* x2, i
                        1.0f / ((float)HW * (float)(C / groups)), eps);
     LCM_CHECK_LAUNCH("gn_finalize_affine");
     return LCM_OK;
+}
+
+static int launch_gn_apply(const void* x, int C1, const void* x2, int C2, const float* scale, const float* shift, void* out,
+                           int B, int HW, int silu, hipStream_t s) {
+    const int C = C1 + C2, ncc = C >> 3;
+    const int nrl = ncc <= 256 ? 256 / ncc : 1;
+    long long rows = ((long long)B * HW + 1023) / 1024;
+    if (rows < nrl) rows = nrl;
+    if (rows > 16ll * nrl) rows = 16ll * nrl;
+    const int rows_per_wg = (int)rows;
+    hipLaunchKernelGGL(gn_apply_kernel, dim3((HW + rows_per_wg - 1) / rows_per_wg, B), dim3(256), 0, s,
+                       (const half_t*)x, C1, (const half_t*)x2, C2, scale, shift, (half_t*)out, HW, silu, rows_per_wg);
+    LCM_CHECK_LAUNCH("gn_apply");
+    return LCM_OK;
+}
+
+extern "C" int lcm_groupnorm_from_stats_f16(const void* x, int C1, const void* x2, int C2, const void* stats1, int P1,
+                                            const void* stats2, int P2, const void* gamma, const void* beta, void* out,
+                                            int B, int HW, int groups, float eps, int silu, void* ws, void* stream) {
+    LCM_REQUIRE(x && stats1 && gamma && beta && out && ws, "groupnorm_from_stats: null pointer");
+    if (!x2) C2 = 0;
+    const int C = C1 + C2;
+    LCM_REQUIRE(B > 0 && HW > 0 && groups > 0 && groups <= 64 && P1 > 0, "groupnorm_from_stats: bad shape");
+    LCM_REQUIRE(C1 % 8 == 0 && C2 % 8 == 0 && C % groups == 0 && C <= GN_MAXC, "groupnorm_from_stats: bad channels %d+%d", C1, C2);
+    LCM_REQUIRE(C2 == 0 || (stats2 && P2 > 0), "groupnorm_from_stats: second source needs its statistics");
+    hipStream_t s = (hipStream_t)stream;
+    float* scale = (float*)ws;
+    float* shift = scale + (long long)B * C;
+    hipLaunchKernelGGL(gn_finalize_from_stats_kernel, dim3(B * groups), dim3(256), 0, s, (const float*)stats1, P1, C1,
+                       (const float*)stats2, P2, C2, (const half_t*)gamma, (const half_t*)beta, scale, shift, groups,
+                       1.0f / ((float)HW * (float)(C / groups)), eps);
+    LCM_CHECK_LAUNCH("gn_finalize_from_stats");
+    return launch_gn_apply(x, C1, x2, C2, scale, shift, out, B, HW, silu, s);
 }
 
 // ---------------------------------------------------------------------------------------------

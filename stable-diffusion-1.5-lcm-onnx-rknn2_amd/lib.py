@@ -32,8 +32,9 @@ _vp, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
 
 _SIGS = {
     "lcm_gemm_f16": [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _i,
-                     _i64, _i64, _i64, _vp],
-    "lcm_conv3x3_f16": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+                     _i64, _i64, _i64, _vp, _i, C.POINTER(_i), _vp],
+    "lcm_conv3x3_f16": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, C.POINTER(_i), _vp],
+    "lcm_groupnorm_from_stats_f16": [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp],
     "lcm_conv3x3_c4_f32in": [_vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "lcm_conv3x3_smalln": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "lcm_groupnorm_f16": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp],
@@ -57,7 +58,8 @@ _SIGS = {
     "lcm_set_conv_impl": [_i],
     "lcm_plan_set": [_i] * 9,
     "lcm_plan_clear": [],
-    "lcm_conv3x3_gn_f16": [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "lcm_conv3x3_gn_f16": [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp,
+                           C.POINTER(_i), _vp],
     "lcm_groupnorm_affine_f16": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp],
     "lcm_device_info": [_i, C.c_char_p, _i, C.POINTER(_i), C.POINTER(C.c_uint64)],
 }

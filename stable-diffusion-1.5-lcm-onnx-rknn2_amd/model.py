@@ -18,6 +18,11 @@ from .config import TEXT_SEQ_LEN, unet_config, vae_config
 from .packing import pack_conv1x1, pack_conv3x3, pack_geglu
 
 
+import os
+
+FUSED_GN_STATS = os.environ.get("LCM_FUSED_GN_STATS", "1") != "0"
+
+
 class _Buffers:
     def __init__(self, device):
         self.device = device
@@ -45,9 +50,30 @@ class _Net:
         self.w = {}
         self.buf = _Buffers(device)
         self._gn_ws = None
+        self._stats = {}
 
     def _put(self, name, t, dtype=torch.float16):
         self.w[name] = _dev(t, self.device, dtype)
+
+    def stats(self, role, M, C):
+        """Per-role holder of the producer-written GroupNorm statistics of an [M, C] tensor."""
+        key = ("stats", role, M, C)
+        st = self._stats.get(key)
+        if st is None:
+            st = ops.Stats(torch.zeros(ops.stats_floats(M, C), dtype=torch.float32, device=self.device))
+            self._stats[key] = st
+        return st
+
+    def norm(self, x, gamma, beta, out, B, HW, C1, *, x_st=None, x2=None, C2=0, x2_st=None, eps=1e-5, silu=True):
+        """GroupNorm(+SiLU) of [x | x2]: from the producers' fused statistics when every source has them
+        (finalize + apply, no statistics pass over the data), else the standalone three-kernel form."""
+        C = C1 + C2
+        ws = self.gn_ws(B, HW, C)
+        if FUSED_GN_STATS and x_st is not None and x_st.P > 0 and (x2 is None or (x2_st is not None and x2_st.P > 0)):
+            ops.groupnorm_from_stats(x, gamma, beta, out, B, HW, C1, x_st, ws, x2=x2, C2=C2, st2=x2_st, eps=eps, silu=silu)
+        else:
+            ops.groupnorm(x, gamma, beta, out, B, HW, C1, ws, x2=x2, C2=C2, eps=eps, silu=silu)
+        return out
 
     def gn_ws(self, B, HW, C):
         need = ops.groupnorm_ws_bytes(B, HW, C) // 4
@@ -72,25 +98,26 @@ class _Net:
         if temb_list is not None:
             temb_list.append((p, sd[f"{p}.time_emb_proj.weight"], sd[f"{p}.time_emb_proj.bias"]))
 
-    def resnet(self, p, x, C1, Cout, B, H, W, eps, x2=None, C2=0, rowadd=None, out_role="res_out"):
+    def resnet(self, p, x, C1, Cout, B, H, W, eps, x2=None, C2=0, rowadd=None, out_role="res_out", x_st=None, x2_st=None):
+        """-> (out, out_stats).  x_st / x2_st: fused statistics of the inputs (None: compute them standalone)."""
         HW, M, Cin = H * W, B * H * W, C1 + C2
         w = self.w
         hn = self.buf.get("gn", M, Cin)
-        ops.groupnorm(x, w[p + ".norm1.g"], w[p + ".norm1.b"], hn, B, HW, C1, self.gn_ws(B, HW, Cin), x2=x2, C2=C2,
-                      eps=eps, silu=True)
+        self.norm(x, w[p + ".norm1.g"], w[p + ".norm1.b"], hn, B, HW, C1, x_st=x_st, x2=x2, C2=C2, x2_st=x2_st, eps=eps)
         h1 = self.buf.get("conv1", M, Cout)
-        ops.conv3x3(hn, w[p + ".conv1.w"], h1, B, H, W, Cin, Cout, bias=w[p + ".conv1.b"], rowadd=rowadd)
+        h1_st = self.stats("conv1", M, Cout)
+        ops.conv3x3(hn, w[p + ".conv1.w"], h1, B, H, W, Cin, Cout, bias=w[p + ".conv1.b"], rowadd=rowadd, stats=h1_st)
         hn2 = self.buf.get("gn", M, Cout)
-        ops.groupnorm(h1, w[p + ".norm2.g"], w[p + ".norm2.b"], hn2, B, HW, Cout, self.gn_ws(B, HW, Cout), eps=eps,
-                      silu=True)
+        self.norm(h1, w[p + ".norm2.g"], w[p + ".norm2.b"], hn2, B, HW, Cout, x_st=h1_st, eps=eps)
         if (p + ".sc.w") in w:
             sc = self.buf.get("shortcut", M, Cout)
             ops.gemm(x, w[p + ".sc.w"], sc, bias=w[p + ".sc.b"], a2=x2)
         else:
             sc = x
         out = self.buf.get(out_role, M, Cout)
-        ops.conv3x3(hn2, w[p + ".conv2.w"], out, B, H, W, Cout, Cout, bias=w[p + ".conv2.b"], res=sc)
-        return out
+        out_st = self.stats(out_role, M, Cout)
+        ops.conv3x3(hn2, w[p + ".conv2.w"], out, B, H, W, Cout, Cout, bias=w[p + ".conv2.b"], res=sc, stats=out_st)
+        return out, out_st
 
 
 # ==================================================================================================
@@ -204,16 +231,16 @@ class UNetHip(_Net):
         ops.linear_smallm(temb, w["temb_all.w"], ta, B, self.temb_total, self.temb_dim, bias=w["temb_all.b"], silu_in=True)
         return ta
 
-    def _res(self, p, x, C1, Cout, B, H, W, ta, x2=None, C2=0, out_role="res_out"):
+    def _res(self, p, x, C1, Cout, B, H, W, ta, x2=None, C2=0, out_role="res_out", x_st=None, x2_st=None):
         off, n = self.temb_off[p]
         return self.resnet(p, x, C1, Cout, B, H, W, self.cfg["norm_eps"], x2=x2, C2=C2, rowadd=ta[:, off:off + n],
-                           out_role=out_role)
+                           out_role=out_role, x_st=x_st, x2_st=x2_st)
 
-    def transformer(self, p, x, C, B, H, W, kv_all, out_role):
+    def transformer(self, p, x, C, B, H, W, kv_all, out_role, x_st=None):
         w, heads = self.w, self.heads
         HW, M, d = H * W, B * H * W, C // heads
         hn = self.buf.get("gn", M, C)
-        ops.groupnorm(x, w[p + ".norm.g"], w[p + ".norm.b"], hn, B, HW, C, self.gn_ws(B, HW, C), eps=1e-6, silu=False)
+        self.norm(x, w[p + ".norm.g"], w[p + ".norm.b"], hn, B, HW, C, x_st=x_st, eps=1e-6, silu=False)
         h = self.buf.get("tf_h", M, C)
         ops.gemm(hn, w[p + ".proj_in.w"], h, bias=w[p + ".proj_in.b"])
         n = self.buf.get("tf_ln", M, C)
@@ -236,8 +263,9 @@ class UNetHip(_Net):
         ops.gemm(n, w[p + ".ff1.w"], ff, bias=w[p + ".ff1.b"], epilogue=1)
         ops.gemm(ff, w[p + ".ff2.w"], h, bias=w[p + ".ff2.b"], res=h)
         out = self.buf.get(out_role, M, C)
-        ops.gemm(h, w[p + ".proj_out.w"], out, bias=w[p + ".proj_out.b"], res=x)
-        return out
+        out_st = self.stats(out_role, M, C)
+        ops.gemm(h, w[p + ".proj_out.w"], out, bias=w[p + ".proj_out.b"], res=x, stats=out_st, stats_hw=HW)
+        return out, out_st
 
     def forward(self, lat, t, kv_all, wemb, B, h, w_, eps_out, taps=None):
         """lat fp32 [B,4,h,w] -> eps_out fp32 [B,h,w,4] (pixel-major)."""
@@ -248,8 +276,8 @@ class UNetHip(_Net):
         H, W = h, w_
         x = self.buf.get("skip0", B * H * W, boc[0])
         ops.conv3x3_c4(lat, wt["conv_in.w"], x, B, H, W, boc[0], bias=wt["conv_in.b"])
-        skips = [(x, boc[0])]
-        ch, ns = boc[0], 1
+        skips = [(x, boc[0], None)]          # (tensor, channels, fused statistics or None)
+        ch, ns, st = boc[0], 1, None
 
         def tap(name, t_, C, H_, W_):
             if taps is not None:
@@ -260,48 +288,50 @@ class UNetHip(_Net):
             for j in range(cfg["layers_per_block"]):
                 p = f"down_blocks.{i}.resnets.{j}"
                 attn = cfg["down_attn"][i]
-                x = self._res(p, x, ch, boc[i], B, H, W, ta, out_role="res_out" if attn else f"skip{ns}")
+                x, st = self._res(p, x, ch, boc[i], B, H, W, ta, out_role="res_out" if attn else f"skip{ns}", x_st=st)
                 ch = boc[i]
                 tap(p, x, ch, H, W)
                 if attn:
                     p = f"down_blocks.{i}.attentions.{j}"
-                    x = self.transformer(p, x, ch, B, H, W, kv_all, f"skip{ns}")
+                    x, st = self.transformer(p, x, ch, B, H, W, kv_all, f"skip{ns}", x_st=st)
                     tap(p, x, ch, H, W)
-                skips.append((x, ch))
+                skips.append((x, ch, st))
                 ns += 1
             if i < nb - 1:
                 p = f"down_blocks.{i}.downsamplers.0.conv"
                 y = self.buf.get(f"skip{ns}", B * (H // 2) * (W // 2), ch)
-                ops.conv3x3(x, wt[p + ".w"], y, B, H, W, ch, ch, bias=wt[p + ".b"], stride=2)
+                st = self.stats(f"skip{ns}", B * (H // 2) * (W // 2), ch)
+                ops.conv3x3(x, wt[p + ".w"], y, B, H, W, ch, ch, bias=wt[p + ".b"], stride=2, stats=st)
                 H, W, x = H // 2, W // 2, y
-                skips.append((x, ch))
+                skips.append((x, ch, st))
                 ns += 1
-        x = self._res("mid_block.resnets.0", x, ch, ch, B, H, W, ta)
-        x = self.transformer("mid_block.attentions.0", x, ch, B, H, W, kv_all, "tf_out")
-        x = self._res("mid_block.resnets.1", x, ch, ch, B, H, W, ta, out_role="cur")
+        x, st = self._res("mid_block.resnets.0", x, ch, ch, B, H, W, ta, x_st=st)
+        x, st = self.transformer("mid_block.attentions.0", x, ch, B, H, W, kv_all, "tf_out", x_st=st)
+        x, st = self._res("mid_block.resnets.1", x, ch, ch, B, H, W, ta, out_role="cur", x_st=st)
         tap("mid_block.resnets.1", x, ch, H, W)
         rboc = tuple(reversed(boc))
         up_attn = tuple(reversed(cfg["down_attn"]))
         for i in range(nb):
             for j in range(cfg["layers_per_block"] + 1):
-                s, sc = skips.pop()
+                s, sc, s_st = skips.pop()
                 p = f"up_blocks.{i}.resnets.{j}"
-                x = self._res(p, x, ch, rboc[i], B, H, W, ta, x2=s, C2=sc, out_role="res_out" if up_attn[i] else "cur")
+                x, st = self._res(p, x, ch, rboc[i], B, H, W, ta, x2=s, C2=sc, out_role="res_out" if up_attn[i] else "cur",
+                                  x_st=st, x2_st=s_st)
                 ch = rboc[i]
                 tap(p, x, ch, H, W)
                 if up_attn[i]:
                     p = f"up_blocks.{i}.attentions.{j}"
-                    x = self.transformer(p, x, ch, B, H, W, kv_all, "cur")
+                    x, st = self.transformer(p, x, ch, B, H, W, kv_all, "cur", x_st=st)
                     tap(p, x, ch, H, W)
             if i < nb - 1:
                 p = f"up_blocks.{i}.upsamplers.0.conv"
                 y = self.buf.get("ups", B * 4 * H * W, ch)
-                ops.conv3x3(x, wt[p + ".w"], y, B, H, W, ch, ch, bias=wt[p + ".b"], ups=1)
+                st = self.stats("ups", B * 4 * H * W, ch)
+                ops.conv3x3(x, wt[p + ".w"], y, B, H, W, ch, ch, bias=wt[p + ".b"], ups=1, stats=st)
                 H, W, x = 2 * H, 2 * W, y
                 tap(f"up_blocks.{i}.upsamplers.0", x, ch, H, W)
         hn = self.buf.get("gn", B * H * W, ch)
-        ops.groupnorm(x, wt["conv_norm_out.g"], wt["conv_norm_out.b"], hn, B, H * W, ch, self.gn_ws(B, H * W, ch),
-                      eps=cfg["norm_eps"], silu=True)
+        self.norm(x, wt["conv_norm_out.g"], wt["conv_norm_out.b"], hn, B, H * W, ch, x_st=st, eps=cfg["norm_eps"])
         ops.conv3x3_smalln(hn, wt["conv_out.w"], eps_out, B, H, W, ch, cfg["out_channels"], bias=wt["conv_out.b"], mode=0)
         return eps_out
 
@@ -339,11 +369,11 @@ class VAEDecoderHip(_Net):
         self._put("conv_out.w", pack_conv3x3(sd["decoder.conv_out.weight"]))
         self._put("conv_out.b", sd["decoder.conv_out.bias"])
 
-    def mid_attention(self, x, C, B, H, W):
+    def mid_attention(self, x, C, B, H, W, x_st=None):
         w = self.w
         S, M = H * W, B * H * W
         hn = self.buf.get("gn", M, C)
-        ops.groupnorm(x, w["attn.norm.g"], w["attn.norm.b"], hn, B, S, C, self.gn_ws(B, S, C), eps=1e-6, silu=False)
+        self.norm(x, w["attn.norm.g"], w["attn.norm.b"], hn, B, S, C, x_st=x_st, eps=1e-6, silu=False)
         q, k, v = (self.buf.get(f"attn_{n}", M, C) for n in "qkv")
         for n, t in (("to_q", q), ("to_k", k), ("to_v", v)):
             ops.gemm(hn, w[f"attn.{n}.w"], t, bias=w[f"attn.{n}.b"])
@@ -356,8 +386,9 @@ class VAEDecoderHip(_Net):
         o = self.buf.get("attn_o", M, C)
         ops.gemm(sc, vt, o, M=S, N=C, K=S, lda=S, ldo=C, batch=B, strideA=S * S, strideW=C * S, strideO=S * C)
         out = self.buf.get("res_out2", M, C)
-        ops.gemm(o, w["attn.o.w"], out, bias=w["attn.o.b"], res=x)
-        return out
+        out_st = self.stats("res_out2", M, C)
+        ops.gemm(o, w["attn.o.w"], out, bias=w["attn.o.b"], res=x, stats=out_st, stats_hw=S)
+        return out, out_st
 
     def decode(self, lat, B, h, w_, rgb_out, img_f32=None, taps=None):
         """lat fp32 [B,4,h,w] (UNet space) -> rgb_out u8 [B,8h,8w,3]; optional fp32 NHWC image copy."""
@@ -374,28 +405,29 @@ class VAEDecoderHip(_Net):
         ops.conv3x3_c4(lat, wt["conv_in.w"], x, B, H, W, ch, bias=wt["conv_in.b"], pre_w=wt["pq.w"], pre_b=wt["pq.b"],
                        in_scale=1.0 / cfg["scaling_factor"])
         tap("decoder.conv_in", x, ch, H, W)
-        x = self.resnet("decoder.mid_block.resnets.0", x, ch, ch, B, H, W, 1e-6)
+        x, st = self.resnet("decoder.mid_block.resnets.0", x, ch, ch, B, H, W, 1e-6)
         tap("decoder.mid_block.resnets.0", x, ch, H, W)
-        x = self.mid_attention(x, ch, B, H, W)
+        x, st = self.mid_attention(x, ch, B, H, W, x_st=st)
         tap("decoder.mid_block.attentions.0", x, ch, H, W)
-        x = self.resnet("decoder.mid_block.resnets.1", x, ch, ch, B, H, W, 1e-6, out_role="cur")
+        x, st = self.resnet("decoder.mid_block.resnets.1", x, ch, ch, B, H, W, 1e-6, out_role="cur", x_st=st)
         rboc = tuple(reversed(boc))
         nb = len(boc)
         roles = ("res_out", "cur")
         for i in range(nb):
             for j in range(cfg["layers_per_block"] + 1):
                 p = f"decoder.up_blocks.{i}.resnets.{j}"
-                x = self.resnet(p, x, ch, rboc[i], B, H, W, 1e-6, out_role=roles[j & 1])
+                x, st = self.resnet(p, x, ch, rboc[i], B, H, W, 1e-6, out_role=roles[j & 1], x_st=st)
                 ch = rboc[i]
                 tap(p, x, ch, H, W)
             if i < nb - 1:
                 p = f"decoder.up_blocks.{i}.upsamplers.0.conv"
                 y = self.buf.get("ups", B * 4 * H * W, ch)
-                ops.conv3x3(x, wt[p + ".w"], y, B, H, W, ch, ch, bias=wt[p + ".b"], ups=1)
+                st = self.stats("ups", B * 4 * H * W, ch)
+                ops.conv3x3(x, wt[p + ".w"], y, B, H, W, ch, ch, bias=wt[p + ".b"], ups=1, stats=st)
                 H, W, x = 2 * H, 2 * W, y
                 tap(f"decoder.up_blocks.{i}.upsamplers.0", x, ch, H, W)
         hn = self.buf.get("gn", B * H * W, ch)
-        ops.groupnorm(x, wt["norm_out.g"], wt["norm_out.b"], hn, B, H * W, ch, self.gn_ws(B, H * W, ch), eps=1e-6, silu=True)
+        self.norm(x, wt["norm_out.g"], wt["norm_out.b"], hn, B, H * W, ch, x_st=st, eps=1e-6)
         ops.conv3x3_smalln(hn, wt["conv_out.w"], rgb_out, B, H, W, ch, cfg["out_channels"], bias=wt["conv_out.b"], mode=1,
                            out_f32=img_f32)
         return rgb_out

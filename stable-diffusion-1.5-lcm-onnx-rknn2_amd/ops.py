@@ -59,10 +59,35 @@ def tile_config(M, N, batch=1):
     return f"{c // 1000}x{c % 1000}"
 
 
+class Stats:
+    """Producer-written GroupNorm partial statistics of one tensor: fp32 [B*P][C][2] + the slab count P."""
+
+    __slots__ = ("buf", "P")
+
+    def __init__(self, buf):
+        self.buf = buf
+        self.P = 0
+
+
+def stats_floats(M, N):
+    """fp32 elements that always suffice for the fused statistics of an [M, N] output: slabs are >= 32 rows for the
+    tile epilogues (M/32 + padding patches) and at most max(M/32, 256) for a split-K reduce."""
+    return 2 * N * (max(M // 16, 256) + 64)
+
+
+def _stats_args(stats):
+    if stats is None:
+        return None, None
+    sp = C.c_int(0)
+    return _p(stats.buf), sp
+
+
 def gemm(a, w, out, *, bias=None, res=None, rowadd=None, rows_per_batch=0, a2=None, epilogue=0, out_scale=1.0,
-         M=None, N=None, K=None, lda=None, ldo=None, batch=1, strideA=0, strideW=0, strideO=0):
-    """out[m][n] = out_scale * sum_k [a|a2][m][k] w[n][k] + bias + rowadd + res  (see include/lcm_hip.h)."""
+         M=None, N=None, K=None, lda=None, ldo=None, batch=1, strideA=0, strideW=0, strideO=0, stats=None, stats_hw=0):
+    """out[m][n] = out_scale * sum_k [a|a2][m][k] w[n][k] + bias + rowadd + res  (see include/lcm_hip.h).
+    stats: optional ``Stats`` to receive the fused GroupNorm statistics of ``out`` (stats.P == 0 afterwards: not produced)."""
     L = _lib.load()
+    sbuf, sp = _stats_args(stats)
     M = a.shape[0] if M is None else M
     K1 = a.shape[-1] if a2 is not None else 0
     K = (a.shape[-1] + (a2.shape[-1] if a2 is not None else 0)) if K is None else K
@@ -72,7 +97,7 @@ def gemm(a, w, out, *, bias=None, res=None, rowadd=None, rows_per_batch=0, a2=No
     if RECORD is not None:
         kw = dict(bias=bias, res=res, rowadd=rowadd, rows_per_batch=rows_per_batch, a2=a2, epilogue=epilogue,
                   out_scale=out_scale, M=M, N=N, K=K, lda=lda, ldo=ldo, batch=batch, strideA=strideA, strideW=strideW,
-                  strideO=strideO)
+                  strideO=strideO, stats=stats, stats_hw=stats_hw)
         RECORD.append(((0, M, N, K, batch), dict(splittable=(epilogue == 0 and batch == 1), halo=False),
                        lambda: gemm(a, w, out, **kw)))
     with _Timed("gemm", tile_config(M, N, batch) if PROFILE is not None else "", 2.0 * M * N * K * batch,
@@ -80,43 +105,54 @@ def gemm(a, w, out, *, bias=None, res=None, rowadd=None, rows_per_batch=0, a2=No
         rc = L.lcm_gemm_f16(_p(a), lda, _p(a2), a2.stride(0) if a2 is not None else 0, K1, _p(w), _p(bias), _p(rowadd),
                             rowadd.stride(0) if rowadd is not None else 0, rows_per_batch,
                             _p(res), res.stride(0) if res is not None else 0, _p(out), ldo,
-                            M, N, K, epilogue, float(out_scale), batch, strideA, strideW, strideO, _stream())
+                            M, N, K, epilogue, float(out_scale), batch, strideA, strideW, strideO,
+                            sbuf, stats_hw, C.byref(sp) if sp is not None else None, _stream())
+    if stats is not None:
+        stats.P = sp.value
     _lib.check(rc, "lcm_gemm_f16")
     return out
 
 
-def conv3x3(x, w, out, B, H, W, Cin, Cout, *, bias=None, rowadd=None, res=None, stride=1, ups=0):
+def conv3x3(x, w, out, B, H, W, Cin, Cout, *, bias=None, rowadd=None, res=None, stride=1, ups=0, stats=None):
     L = _lib.load()
+    sbuf, sp = _stats_args(stats)
     Ho, Wo = ((2 * H, 2 * W) if ups else ((H + 1) // 2, (W + 1) // 2) if stride == 2 else (H, W))
     Mo = B * Ho * Wo
     if RECORD is not None:
-        kw = dict(bias=bias, rowadd=rowadd, res=res, stride=stride, ups=ups)
+        kw = dict(bias=bias, rowadd=rowadd, res=res, stride=stride, ups=ups, stats=stats)
         key = (1, Mo, Cout, 9 * Cin, 1) if stride == 2 else (2, Mo, Cout, 9 * Cin, (Wo << 1))
         RECORD.append((key, dict(splittable=True, halo=stride == 1, W=Wo), lambda: conv3x3(x, w, out, B, H, W, Cin, Cout, **kw)))
     with _Timed("conv3x3", tile_config(Mo, Cout) if PROFILE is not None else "", 2.0 * Mo * Cout * 9 * Cin,
                 2.0 * (B * H * W * Cin + 9 * Cin * Cout + Mo * Cout)):
         rc = L.lcm_conv3x3_f16(_p(x), _p(w), _p(bias), _p(rowadd), rowadd.stride(0) if rowadd is not None else 0,
-                               _p(res), _p(out), B, H, W, Cin, Cout, stride, ups, _stream())
+                               _p(res), _p(out), B, H, W, Cin, Cout, stride, ups, sbuf,
+                               C.byref(sp) if sp is not None else None, _stream())
+    if stats is not None:
+        stats.P = sp.value
     _lib.check(rc, "lcm_conv3x3_f16")
     return out
 
 
 def conv3x3_gn(x, w, out, B, H, W, C1, Cout, *, x2=None, C2=0, gn_scale=None, gn_shift=None, silu=True, bias=None,
-               rowadd=None, res=None, ups=0):
+               rowadd=None, res=None, ups=0, stats=None):
     """Fused [GroupNorm-apply (+SiLU)] -> conv3x3 (stride 1) over the channel concat [x | x2]."""
     L = _lib.load()
+    sbuf, sp = _stats_args(stats)
     Cin = C1 + (C2 if x2 is not None else 0)
     Ho, Wo = (2 * H, 2 * W) if ups else (H, W)
     Mo = B * Ho * Wo
     if RECORD is not None:
-        kw = dict(x2=x2, C2=C2, gn_scale=gn_scale, gn_shift=gn_shift, silu=silu, bias=bias, rowadd=rowadd, res=res, ups=ups)
+        kw = dict(x2=x2, C2=C2, gn_scale=gn_scale, gn_shift=gn_shift, silu=silu, bias=bias, rowadd=rowadd, res=res, ups=ups,
+                  stats=stats)
         RECORD.append(((2, Mo, Cout, 9 * Cin, (Wo << 1) | (1 if gn_scale is not None else 0)),
                        dict(splittable=True, halo=True, W=Wo), lambda: conv3x3_gn(x, w, out, B, H, W, C1, Cout, **kw)))
     with _Timed("conv3x3", "halo", 2.0 * Mo * Cout * 9 * Cin, 2.0 * (B * H * W * Cin + 9 * Cin * Cout + Mo * Cout)):
         rc = L.lcm_conv3x3_gn_f16(_p(x), C1, _p(x2), C2 if x2 is not None else 0, _p(gn_scale), _p(gn_shift),
                                   1 if silu else 0, _p(w), _p(bias), _p(rowadd),
                                   rowadd.stride(0) if rowadd is not None else 0, _p(res), _p(out), B, H, W, Cout, ups,
-                                  _stream())
+                                  sbuf, C.byref(sp) if sp is not None else None, _stream())
+    if stats is not None:
+        stats.P = sp.value
     _lib.check(rc, "lcm_conv3x3_gn_f16")
     return out
 
@@ -156,6 +192,16 @@ def groupnorm(x, gamma, beta, out, B, HW, C1, ws, *, x2=None, C2=0, groups=32, e
     rc = L.lcm_groupnorm_f16(_p(x), C1, _p(x2), C2, _p(gamma), _p(beta), _p(out), B, HW, groups, float(eps),
                              1 if silu else 0, _p(ws), _stream())
     _lib.check(rc, "lcm_groupnorm_f16")
+    return out
+
+
+def groupnorm_from_stats(x, gamma, beta, out, B, HW, C1, st1, ws, *, x2=None, C2=0, st2=None, groups=32, eps=1e-5, silu=True):
+    """GroupNorm(+SiLU) of [x | x2] using producer-written statistics (``Stats`` objects with P > 0)."""
+    L = _lib.load()
+    rc = L.lcm_groupnorm_from_stats_f16(_p(x), C1, _p(x2), C2 if x2 is not None else 0, _p(st1.buf), st1.P,
+                                        _p(st2.buf) if st2 is not None else None, st2.P if st2 is not None else 0,
+                                        _p(gamma), _p(beta), _p(out), B, HW, groups, float(eps), 1 if silu else 0, _p(ws), _stream())
+    _lib.check(rc, "lcm_groupnorm_from_stats_f16")
     return out
 
 

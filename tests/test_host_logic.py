@@ -31,11 +31,11 @@ def test_abi_argument_validation_without_gpu():
     import ctypes as C
     from sdlcm_amd import lib
     L = lib.load()
-    rc = L.lcm_gemm_f16(None, 0, None, 0, 0, None, None, None, 0, 0, None, 0, None, 0, 1, 64, 64, 0, 1.0, 1, 0, 0, 0, None)
+    rc = L.lcm_gemm_f16(None, 0, None, 0, 0, None, None, None, 0, 0, None, 0, None, 0, 1, 64, 64, 0, 1.0, 1, 0, 0, 0, None, 0, None, None)
     assert rc == -1 and b"null pointer" in L.lcm_last_error()
     buf = C.create_string_buffer(16)
     p = C.cast(buf, C.c_void_p)
-    rc = L.lcm_gemm_f16(p, 8, None, 0, 0, p, None, None, 0, 0, None, 0, p, 8, 4, 64, 100, 0, 1.0, 1, 0, 0, 0, None)
+    rc = L.lcm_gemm_f16(p, 8, None, 0, 0, p, None, None, 0, 0, None, 0, p, 8, 4, 64, 100, 0, 1.0, 1, 0, 0, 0, None, 0, None, None)
     assert rc == -1 and b"multiple of 64" in L.lcm_last_error()
     rc = L.lcm_attention_f16(p, 8, p, 8, p, 8, p, 8, 1, 8, 4, 4, 48, 1.0, None)
     assert rc == -1 and b"head_dim" in L.lcm_last_error()

@@ -152,6 +152,72 @@ def test_conv3x3_gn_fused(B, H, W, C1, C2, Cout, ups, silu, splitk):
     close(from_nhwc(out, B, Ho, Wo), ref, rtol=6e-3, what="conv3x3_gn")
 
 
+def _ref_gn(xc, B, HW, C, gamma, beta, eps, silu):
+    ref = F.group_norm(xc.float().reshape(B, HW, C).permute(0, 2, 1), 32, gamma.float(), beta.float(), eps)
+    if silu:
+        ref = F.silu(ref)
+    return ref.permute(0, 2, 1).reshape(B * HW, C)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,splitk,stride", [
+    (2, 16, 16, 320, 320, False, 1), (1, 64, 64, 320, 640, False, 1), (1, 8, 8, 1280, 1280, True, 1),
+    (1, 16, 16, 640, 1280, True, 1), (2, 24, 40, 128, 128, False, 1), (1, 32, 32, 320, 320, False, 2),
+    (1, 4, 4, 1280, 1280, True, 1), (1, 128, 128, 128, 256, False, 1)])
+def test_fused_groupnorm_stats_from_conv(B, H, W, Cin, Cout, splitk, stride):
+    """conv3x3 writes the GroupNorm statistics of its output in the epilogue (or split-K reduce); the
+    finalize+apply pair must reproduce F.group_norm of the stored fp16 tensor."""
+    x = to_nhwc(rnd(B, Cin, H, W, seed=1)).to(DEV)
+    w = pack3x3(rnd(Cout, Cin, 3, 3, seed=2, scale=(9 * Cin) ** -0.5)).to(DEV)
+    b = rnd(Cout, seed=3).to(DEV)
+    Ho, Wo = ((H + 1) // 2, (W + 1) // 2) if stride == 2 else (H, W)
+    HW = Ho * Wo
+    out = torch.empty(B * HW, Cout, dtype=torch.float16, device=DEV)
+    st = ops.Stats(torch.zeros(ops.stats_floats(B * HW, Cout), dtype=torch.float32, device=DEV))
+    skws = torch.empty(16 << 20, dtype=torch.float32, device=DEV)
+    ops.set_workspace(skws if splitk else None)
+    try:
+        ops.conv3x3(x, w, out, B, H, W, Cin, Cout, bias=b, stride=stride, stats=st)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_workspace(None)
+    gamma, beta = (1 + 0.1 * rnd(Cout, seed=4).float()).half(), rnd(Cout, seed=5, scale=0.1)
+    ref = _ref_gn(out.cpu(), B, HW, Cout, gamma, beta, 1e-5, True)
+    y = torch.empty_like(out)
+    ws = torch.empty(ops.groupnorm_ws_bytes(B, HW, Cout) // 4 + 16, dtype=torch.float32, device=DEV)
+    if st.P > 0:
+        ops.groupnorm_from_stats(out, gamma.to(DEV), beta.to(DEV), y, B, HW, Cout, st, ws)
+        close(y, ref, what=f"gn from fused stats (P={st.P})")
+    else:
+        assert HW % 64 != 0, "statistics should have been produced for this shape"
+
+
+def test_fused_groupnorm_stats_concat_and_gemm():
+    """Statistics from two producers (a gemm with residual and a conv) drive the GroupNorm of their channel concat,
+    with a group straddling the concat boundary (C1=1280, C2=640, 60 channels per group)."""
+    B, H, W, C1, C2 = 1, 16, 16, 1280, 640
+    HW = H * W
+    a = rnd(B * HW, 640, seed=1).to(DEV)
+    w1 = rnd(C1, 640, seed=2, scale=640 ** -0.5).to(DEV)
+    r1 = rnd(B * HW, C1, seed=3).to(DEV)
+    x1 = torch.empty(B * HW, C1, dtype=torch.float16, device=DEV)
+    st1 = ops.Stats(torch.zeros(ops.stats_floats(B * HW, C1), dtype=torch.float32, device=DEV))
+    ops.gemm(a, w1, x1, res=r1, stats=st1, stats_hw=HW)
+    xin = to_nhwc(rnd(B, 320, H, W, seed=4)).to(DEV)
+    w2 = pack3x3(rnd(C2, 320, 3, 3, seed=5, scale=(9 * 320) ** -0.5)).to(DEV)
+    x2 = torch.empty(B * HW, C2, dtype=torch.float16, device=DEV)
+    st2 = ops.Stats(torch.zeros(ops.stats_floats(B * HW, C2), dtype=torch.float32, device=DEV))
+    ops.conv3x3(xin, w2, x2, B, H, W, 320, C2, stats=st2)
+    torch.cuda.synchronize()
+    assert st1.P > 0 and st2.P > 0
+    C = C1 + C2
+    gamma, beta = (1 + 0.1 * rnd(C, seed=6).float()).half(), rnd(C, seed=7, scale=0.1)
+    ref = _ref_gn(torch.cat([x1.cpu(), x2.cpu()], 1), B, HW, C, gamma, beta, 1e-5, True)
+    y = torch.empty(B * HW, C, dtype=torch.float16, device=DEV)
+    ws = torch.empty(ops.groupnorm_ws_bytes(B, HW, C) // 4 + 16, dtype=torch.float32, device=DEV)
+    ops.groupnorm_from_stats(x1, gamma.to(DEV), beta.to(DEV), y, B, HW, C1, st1, ws, x2=x2, C2=C2, st2=st2)
+    close(y, ref, what="gn from fused stats over a concat")
+
+
 def test_conv_halo_matches_row_gather_igemm():
     """The two 3x3 implementations agree to fp32 summation-order noise on a plain conv (border + m-tail)."""
     B, H, W, Cin, Cout = 2, 20, 28, 192, 128
