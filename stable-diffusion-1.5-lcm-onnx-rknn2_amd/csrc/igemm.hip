@@ -321,16 +321,17 @@ __global__ __launch_bounds__(256, S == 1 ? 4 : 2) void igemm2_kernel(IgemmParams
 // Split-K combine: fixed-order sum of the fp32 slabs (bit-reproducible) + the epilogue of the main kernel, and
 // optionally the fused GroupNorm statistics of the result.  A workgroup owns p.reduce_rows consecutive rows; a thread
 // owns one 4-channel group and walks rows, so per-channel sums need only a fixed-order fold over the row lanes.
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(IgemmParams p) {
-    __shared__ float red[2048 * 2];
+#define RED_THREADS 1024
+__global__ __launch_bounds__(RED_THREADS) void splitk_reduce_kernel(IgemmParams p) {
+    __shared__ float red[RED_THREADS * 4 * 2];
     const int n4 = p.N >> 2, tid = threadIdx.x;
     const int r0 = blockIdx.x * p.reduce_rows, r1 = min(p.M, r0 + p.reduce_rows);
     const long long slab = (long long)p.M * p.N;
-    const bool small = n4 <= 256;
-    const int nrl = small ? 256 / n4 : 1;
+    const bool small = n4 <= RED_THREADS;
+    const int nrl = small ? RED_THREADS / n4 : 1;        // row lanes: threads that share a channel group
     const int rl = small ? tid / n4 : 0;
     const bool do_stats = p.stats != nullptr;
-    for (int cg = small ? tid - rl * n4 : tid; cg < n4; cg += 256) {
+    for (int cg = small ? tid - rl * n4 : tid; cg < n4; cg += RED_THREADS) {
         const int n = cg * 4;
         float ss[4] = {0.f, 0.f, 0.f, 0.f}, qq[4] = {0.f, 0.f, 0.f, 0.f};
         if (rl < nrl) {
@@ -369,7 +370,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(IgemmParams p) {
     }
     if (do_stats && small) {
         __syncthreads();
-        for (int c = tid; c < p.N; c += 256) {
+        for (int c = tid; c < p.N; c += RED_THREADS) {
             float s = 0.f, q = 0.f;
             for (int r = 0; r < nrl; ++r) { s += red[(r * p.N + c) * 2]; q += red[(r * p.N + c) * 2 + 1]; }
             float* dst = p.stats + ((long long)blockIdx.x * p.N + c) * 2;
@@ -401,7 +402,7 @@ int lcm_reduce_rows(int M, int hw) {
 
 void lcm_launch_splitk_reduce(IgemmParams& p, hipStream_t s) {
     if (p.reduce_rows <= 0) p.reduce_rows = lcm_reduce_rows(p.M, 0);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((p.M + p.reduce_rows - 1) / p.reduce_rows)), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((p.M + p.reduce_rows - 1) / p.reduce_rows)), dim3(RED_THREADS), 0, s, p);
 }
 
 float* lcm_splitk_workspace(long long* bytes) {

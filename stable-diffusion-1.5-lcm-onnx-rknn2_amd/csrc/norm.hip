@@ -177,28 +177,30 @@ __global__ __launch_bounds__(256) void gn_finalize_from_stats_kernel(const float
     const int bg = blockIdx.x, b = bg / groups, g = bg - b * groups, tid = threadIdx.x;
     const int c_lo = g * cpg, c_hi = c_lo + cpg;
     float s = 0.f, q = 0.f;
-    {   // source 1: channels [c_lo, min(c_hi, C1))
-        const int a = c_lo, e = min(c_hi, C1), w = e - a;
-        if (w > 0) {
-            const int total = P1 * w;
-            for (int i = tid; i < total; i += 256) {
-                const int pp = i / w, c = a + (i - pp * w);
-                const float* v = st1 + (((long long)b * P1 + pp) * C1 + c) * 2;
-                s += v[0]; q += v[1];
-            }
+    // thread -> (slab lane, channel of the group); slabs are walked 4 at a time with independent loads
+    auto accumulate = [&](const float* __restrict__ st, int P, int Cs, int a, int w) {
+        if (w <= 0 || st == nullptr) return;
+        const int spl = 256 / w;                   // slab lanes
+        const int sl = tid / w, jc = tid - sl * w;
+        if (sl >= spl) return;
+        const float* base = st + ((long long)b * P * Cs + a + jc) * 2;
+        const long long stride = (long long)Cs * 2;
+        int pp = sl;
+        for (; pp + 3 * spl < P; pp += 4 * spl) {
+            const float2 v0 = *reinterpret_cast<const float2*>(base + pp * stride);
+            const float2 v1 = *reinterpret_cast<const float2*>(base + (pp + spl) * stride);
+            const float2 v2 = *reinterpret_cast<const float2*>(base + (pp + 2 * spl) * stride);
+            const float2 v3 = *reinterpret_cast<const float2*>(base + (pp + 3 * spl) * stride);
+            s += (v0.x + v1.x) + (v2.x + v3.x);
+            q += (v0.y + v1.y) + (v2.y + v3.y);
         }
-    }
-    {   // source 2: channels [max(c_lo, C1), c_hi)
-        const int a = max(c_lo, C1), e = c_hi, w = e - a;
-        if (w > 0 && st2) {
-            const int total = P2 * w;
-            for (int i = tid; i < total; i += 256) {
-                const int pp = i / w, c = a + (i - pp * w) - C1;
-                const float* v = st2 + (((long long)b * P2 + pp) * C2 + c) * 2;
-                s += v[0]; q += v[1];
-            }
+        for (; pp < P; pp += spl) {
+            const float2 v = *reinterpret_cast<const float2*>(base + pp * stride);
+            s += v.x; q += v.y;
         }
-    }
+    };
+    accumulate(st1, P1, C1, c_lo, min(c_hi, C1) - c_lo);                       // channels of the group in source 1
+    accumulate(st2, P2, C2, max(c_lo, C1) - C1, c_hi - max(c_lo, C1));         // ... and in source 2
     rs[tid] = s; rq[tid] = q;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {

@@ -100,8 +100,8 @@ def test_end_to_end_parity(state, size, steps, seed):
 def test_graph_replay_equals_eager_and_is_deterministic(state):
     hip = state["hip"]
     pe = _embeds(1, seed=9)
+    g1 = hip.generate(pe, [77], 128, 128, 4, 1.0)          # first graph use autotunes the launch plans
     eager = hip.generate(pe, [77], 128, 128, 4, 1.0, want_float=True)
-    g1 = hip.generate(pe, [77], 128, 128, 4, 1.0)
     g2 = hip.generate(pe, [77], 128, 128, 4, 1.0)
     assert hip.plan(1, 16, 16, 4).graph is not None
     assert np.array_equal(g1["rgb"], g2["rgb"]) and np.array_equal(g1["latents"], g2["latents"])
