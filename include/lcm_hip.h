@@ -103,6 +103,9 @@ int lcm_conv3x3_gn_f16(const void* in, int C1, const void* in2, int C2, const vo
 int lcm_groupnorm_affine_f16(const void* x, int C1, const void* x2, int C2, const void* gamma, const void* beta,
                              void* scale_out, void* shift_out, int B, int HW, int groups, float eps, void* ws,
                              void* stream);
+/* launches of the LDS-halo conv with fewer workgroups than this use its pipelined variant (3-stage weight ring,
+ * double-buffered halo) instead of the single-buffer high-occupancy one; default 768 */
+int lcm_set_halo_pipe_threshold(int wgs);
 /* 1 (default): stride-1 3x3 convolutions use the LDS-halo kernel; 0: the row-gather implicit GEMM everywhere */
 int lcm_set_conv_impl(int impl);
 

@@ -192,6 +192,156 @@ __global__ __launch_bounds__(256, 3) void conv_halo_kernel(HaloParams hp) {
     igemm_epilogue<BM, BN>(p, acc, m_of, n_base + wn * (BN / 2), fq, 0, mt * 2 + wm);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Pipelined variant for launches that cannot put 3-4 workgroups on every CU (batch-1 UNet levels, split-K
+// slices): with ~1 workgroup per CU nothing else hides the staging latency, so the weight slices run through a
+// WS-deep LDS-DMA ring with a counted vmcnt (WS-2 slices stay in flight across the single raw barrier per
+// K-step) and the halo is double-buffered, the next chunk's halo being fetched while the current 9 taps run.
+// ------------------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void halo_wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int TH, int TW, int BN, int WS>
+__global__ __launch_bounds__(256, 2) void conv_halo_pipe_kernel(HaloParams hp) {
+    constexpr int BM = TH * TW;
+    constexpr int TM = BM / 32, TN = BN / 32, RW = BN / 32;
+    constexpr int HWD = TW + 2, HROWS = (TH + 2) * HWD, HROWS_PAD = (HROWS + 7) / 8 * 8;
+    constexpr int NV = (HROWS_PAD * 8 + 255) / 256;
+    constexpr int XBYTES = HROWS_PAD * 128, WBYTES = BN * 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* xs0 = smem;                      // two halo buffers
+    char* wsm0 = smem + 2 * XBYTES;        // WS weight-slice buffers
+
+    const IgemmParams& p = hp.g;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, wn = wave >> 1;
+    const int tile = xcd_remap(blockIdx.x, p.mtiles * p.ntiles);
+    const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
+    const int per_img = hp.tiles_y * hp.tiles_x;
+    const int bimg = mt / per_img, tr = mt - bimg * per_img;
+    const int ty = tr / hp.tiles_x, tx = tr - ty * hp.tiles_x;
+    const int y0 = ty * TH, x0 = tx * TW;
+    const int n_base = nt * BN;
+    const int C2 = p.Cin - hp.C1;
+
+    int h_pix[NV];
+    const int pos = tid & 7;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int hr = (tid + 256 * i) >> 3;
+        const int hy = hr / HWD, hx = hr - hy * HWD;
+        int ly = y0 - 1 + hy, lx = x0 - 1 + hx;
+        const bool ok = hr < HROWS && ly >= 0 && ly < hp.H && lx >= 0 && lx < hp.W;
+        if (p.ups) { ly >>= 1; lx >>= 1; }
+        h_pix[i] = ok ? (bimg * p.Hin + ly) * p.Win + lx : -1;
+    }
+    const int w_row0 = tid >> 3;
+    const int w_schunk = (pos ^ (w_row0 & 7)) * 8;
+    const half_t* wptr = p.W + (long long)(n_base + w_row0) * p.K + w_schunk;
+
+    const int frow = lane & 15, fq = lane >> 4;
+    const int q0 = wm * TM * 16 + frow;
+    const int rb0 = (q0 / TW) * HWD + (q0 % TW);
+    constexpr int RB_STEP = (16 / TW) * HWD;
+
+    f4 acc[TN][TM];
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b) acc[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
+
+    const int nchunks = p.Cin >> 6;
+    const int c_begin = (int)((long long)blockIdx.y * nchunks / p.splits);
+    const int c_end = (int)((long long)(blockIdx.y + 1) * nchunks / p.splits);
+    const int T = (c_end - c_begin) * 9;
+
+    auto issue_halo = [&](int c64, int hb) {
+        const int cb = c64 << 6;
+        const bool second = cb >= hp.C1;
+        const half_t* src_base = second ? p.A2 : p.A;
+        const int src_ld = second ? C2 : hp.C1;
+        const int src_c = second ? cb - hp.C1 : cb;
+        char* xs = xs0 + hb * XBYTES;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            if ((wave + 4 * i) * 64 < HROWS_PAD * 8) {
+                const int hr = (tid + 256 * i) >> 3;
+                const half_t* src = h_pix[i] >= 0
+                    ? src_base + (long long)h_pix[i] * src_ld + src_c + ((pos ^ (hr & 7)) << 3)
+                    : g_zero_page_h;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(xs + (wave + 4 * i) * 1024), 16, 0, 0);
+            }
+        }
+    };
+    auto issue_w = [&](int t, int wb) {     // t = flattened (chunk, tap) step
+        const int c64 = c_begin + t / 9, tap = t - (t / 9) * 9;
+        const half_t* wsrc = wptr + (long long)tap * p.Cin + (c64 << 6);
+        char* wsm = wsm0 + wb * WBYTES;
+#pragma unroll
+        for (int i = 0; i < RW; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + (long long)(32 * i) * p.K),
+                                             (__attribute__((address_space(3))) void*)(wsm + (i * 32 + wave * 8) * 128), 16, 0, 0);
+    };
+
+    // prologue: halo of the first chunk, then WS-1 weight slices
+    if (T > 0) issue_halo(c_begin, 0);
+#pragma unroll
+    for (int s = 0; s < WS - 1; ++s)
+        if (s < T) issue_w(s, s);
+
+    int wb = 0;
+    for (int t = 0; t < T; ++t) {
+        const int chunk = t / 9, tap = t - chunk * 9;
+        // W(t) (and, being older, this chunk's halo) must have landed; min(WS-2, T-1-t) newer slices may stay in flight
+        const int newer = T - 1 - t;
+        if (WS >= 4 && newer >= 2) halo_wait_vmcnt<(WS >= 4 ? 2 : 0) * RW>();
+        else if (WS >= 3 && newer >= 1) halo_wait_vmcnt<(WS >= 3 ? 1 : 0) * RW>();
+        else halo_wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (t + WS - 1 < T) issue_w(t + WS - 1, (wb + WS - 1) % WS);
+        if (tap == 0 && c_begin + chunk + 1 < c_end) issue_halo(c_begin + chunk + 1, (chunk + 1) & 1);
+
+        const char* xs = xs0 + (chunk & 1) * XBYTES;
+        const int dy = tap / 3, dx = tap - dy * 3;
+        const int tapoff = dy * HWD + dx;
+        const char* wsr = wsm0 + wb * WBYTES + (wn * (BN / 2)) * 128;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            h8 xf[TM], wf[TN];
+            const int c = kk * 4 + fq;
+#pragma unroll
+            for (int b = 0; b < TM; ++b) {
+                const int r = rb0 + b * RB_STEP + tapoff;
+                xf[b] = *reinterpret_cast<const h8*>(xs + r * 128 + ((c ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int a = 0; a < TN; ++a) {
+                const int r = a * 16 + frow;
+                wf[a] = *reinterpret_cast<const h8*>(wsr + r * 128 + ((c ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int a = 0; a < TN; ++a)
+#pragma unroll
+                for (int b = 0; b < TM; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[a], xf[b], acc[a][b], 0, 0, 0);
+        }
+        wb = (wb + 1 == WS) ? 0 : wb + 1;
+    }
+
+    int m_of[TM];
+#pragma unroll
+    for (int b = 0; b < TM; ++b) {
+        const int q = (wm * TM + b) * 16 + frow;
+        const int y = y0 + q / TW, x = x0 + q % TW;
+        m_of[b] = (y < hp.H && x < hp.W) ? (bimg * hp.H + y) * hp.W + x : -1;
+    }
+    igemm_epilogue<BM, BN>(p, acc, m_of, n_base + wn * (BN / 2), fq, 0, mt * 2 + wm);
+}
+
 // split-K combine kernel lives in igemm.hip
 extern void lcm_launch_splitk_reduce(IgemmParams& p, hipStream_t s);
 extern int lcm_reduce_rows(int M, int hw);
@@ -199,14 +349,30 @@ extern float* lcm_splitk_workspace(long long* bytes);
 extern void lcm_tuning(int* target_wgs, int* max_splits, int* min_wgs);
 extern bool lcm_plan_get(int kind, int M, int N, int K, int aux, int* bm, int* bn, int* splits, int* variant);
 
+static int g_halo_pipe_below = 768;      // workgroup count under which the pipelined (WS=3) variant is used
+
+extern "C" int lcm_set_halo_pipe_threshold(int wgs) { g_halo_pipe_below = wgs; return LCM_OK; }
+
 template <int TH, int TW, int BN, int XFORM>
 static void launch_halo(HaloParams& hp, hipStream_t s) {
     constexpr int HROWS_PAD = ((TH + 2) * (TW + 2) + 7) / 8 * 8;
-    constexpr int smem = HROWS_PAD * 128 + BN * 128;
     hp.tiles_y = (hp.H + TH - 1) / TH;
     hp.tiles_x = (hp.W + TW - 1) / TW;
     hp.g.ntiles = hp.g.N / BN;
     dim3 grid(hp.g.mtiles * hp.g.ntiles, hp.g.splits, 1);
+    if (!XFORM && (long long)grid.x * grid.y < g_halo_pipe_below) {
+        constexpr int WS = 3;
+        constexpr int smem = 2 * HROWS_PAD * 128 + WS * BN * 128;
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_pipe_kernel<TH, TW, BN, WS>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((conv_halo_pipe_kernel<TH, TW, BN, WS>), grid, dim3(256), smem, s, hp);
+        return;
+    }
+    constexpr int smem = HROWS_PAD * 128 + BN * 128;
     hipLaunchKernelGGL((conv_halo_kernel<TH, TW, BN, XFORM>), grid, dim3(256), smem, s, hp);
 }
 

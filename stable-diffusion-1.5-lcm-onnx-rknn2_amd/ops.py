@@ -164,6 +164,10 @@ def groupnorm_affine(x, gamma, beta, scale, shift, B, HW, C1, ws, *, x2=None, C2
     _lib.check(rc, "lcm_groupnorm_affine_f16")
 
 
+def set_halo_pipe_threshold(wgs):
+    _lib.check(_lib.load().lcm_set_halo_pipe_threshold(int(wgs)), "lcm_set_halo_pipe_threshold")
+
+
 def set_conv_impl(impl):
     _lib.check(_lib.load().lcm_set_conv_impl(int(impl)), "lcm_set_conv_impl")
 

@@ -218,6 +218,38 @@ def test_fused_groupnorm_stats_concat_and_gemm():
     close(y, ref, what="gn from fused stats over a concat")
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,ups,splitk", [(2, 12, 20, 128, 192, 0, False), (1, 9, 7, 64, 64, 0, False),
+                                                      (1, 6, 10, 192, 128, 1, False), (1, 64, 64, 320, 320, 0, True),
+                                                      (1, 8, 8, 1280, 1280, 0, True), (2, 16, 16, 640, 1280, 0, True),
+                                                      (1, 1, 1, 1280, 1280, 0, True)])
+def test_conv_halo_pipelined_variant_is_bit_identical(B, H, W, Cin, Cout, ups, splitk):
+    """The pipelined (3-stage weight ring, double-buffered halo) and the single-buffer halo kernels walk K in
+    the same order: outputs must be bit-identical."""
+    x = to_nhwc(rnd(B, Cin, H, W, seed=1)).to(DEV)
+    w = pack3x3(rnd(Cout, Cin, 3, 3, seed=2, scale=(9 * Cin) ** -0.5)).to(DEV)
+    b = rnd(Cout, seed=3).to(DEV)
+    Ho, Wo = (2 * H, 2 * W) if ups else (H, W)
+    ws = torch.empty(16 << 20, dtype=torch.float32, device=DEV)
+    ops.set_workspace(ws if splitk else None)
+    outs = []
+    try:
+        for thr in (0, 1 << 30):
+            ops.set_halo_pipe_threshold(thr)
+            o = torch.empty(B * Ho * Wo, Cout, dtype=torch.float16, device=DEV)
+            ops.conv3x3(x, w, o, B, H, W, Cin, Cout, bias=b, ups=ups)
+            outs.append(o)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_halo_pipe_threshold(768)
+        ops.set_workspace(None)
+    assert torch.equal(outs[0], outs[1])
+    xin = from_nhwc(x.cpu().float(), B, H, W)
+    if ups:
+        xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(xin, w.cpu().float().reshape(Cout, 3, 3, Cin).permute(0, 3, 1, 2), b.cpu().float(), padding=1)
+    close(from_nhwc(outs[1], B, Ho, Wo), ref, what="conv halo pipelined")
+
+
 def test_conv_halo_matches_row_gather_igemm():
     """The two 3x3 implementations agree to fp32 summation-order noise on a plain conv (border + m-tail)."""
     B, H, W, Cin, Cout = 2, 20, 28, 192, 128
