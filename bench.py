@@ -62,30 +62,32 @@ def cpu_baseline(threads):
 
 
 def roofline_leg(pipe, P, guidance):
-    """Live per-launch HIP-event timing of the dominant kernel (implicit-GEMM conv3x3 on MFMA) over one eager
-    pass of the same workload; achieved = algorithmic FLOP of those launches / their summed duration."""
+    """Live per-launch HIP-event timing (recorded by the library around each MFMA kernel on its launch stream) over
+    one eager pass of the same workload, while a spin kernel holds the stream so the host runs ahead of the GPU.
+    achieved = algorithmic FLOP of the dominant kernel instantiation's launches / their summed duration."""
     import torch
     from sdlcm_amd import ops
     ops.PROFILE = []
     with torch.cuda.stream(pipe.stream):
-        # hold the stream while the host enqueues, so the events bracket back-to-back GPU execution
         ops.debug_spin(min(2000000, 150000 + 120000 * P.B))
+        ops.profile_begin()
         pipe._enqueue(P, guidance)
         pipe.stream.synchronize()
+        times = ops.profile_end()
     recs, ops.PROFILE = ops.PROFILE, None
+    assert len(recs) == len(times), (len(recs), len(times))
     agg = {}
-    for r in recs:
-        k = (r["kind"], r["tile"])
-        a = agg.setdefault(k, dict(n=0, flops=0.0, ms=0.0))
-        a["n"] += 1; a["flops"] += r["flops"]; a["ms"] += r["e0"].elapsed_time(r["e1"])
-    (kind, tile), dom = max(agg.items(), key=lambda kv: kv[1]["ms"])
+    for r, (name, ms) in zip(recs, times):
+        a = agg.setdefault(name, dict(n=0, flops=0.0, ms=0.0, kind=r["kind"]))
+        a["n"] += 1; a["flops"] += r["flops"]; a["ms"] += ms
+    name, dom = max(agg.items(), key=lambda kv: kv[1]["ms"])
     ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-    table = {f"{k[0]}[{k[1]}]": {"launches": v["n"], "ms": round(v["ms"], 3),
-                                 "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)} for k, v in agg.items()}
+    table = {k: {"launches": v["n"], "ms": round(v["ms"], 3), "avg_us": round(v["ms"] * 1e3 / v["n"], 2),
+                 "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)} for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
     tot_f = sum(v["flops"] for v in agg.values()); tot_ms = sum(v["ms"] for v in agg.values())
-    return {"bound": "mfma", "kernel": f"igemm_kernel<{tile.replace('x', ',')},{1 if kind == 'conv3x3' else 0}> ({kind})",
+    return {"bound": "mfma", "kernel": f"{name} ({dom['kind']})",
             "achieved": round(ach, 1), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_F16_PEAK_TFLOPS, 4),
-            "launches": dom["n"], "avg_launch_us": round(dom["ms"] * 1e3 / dom["n"], 1), "traffic": None,
+            "launches": dom["n"], "avg_launch_us": round(dom["ms"] * 1e3 / dom["n"], 2), "traffic": None,
             "all_mfma_kernels": {"tflops": round(tot_f / (tot_ms * 1e-3) / 1e12, 1), "ms": round(tot_ms, 3)},
             "by_kernel": table}
 

@@ -177,6 +177,11 @@ int lcm_scheduler_step(const void* eps, const void* eps_uncond, float guidance, 
 /* ---- adaptive_avg_pool2d(lat,(8,8)) -> fp16 [B,4,8,8] (run_job_with_latents, backends/cuda_worker.py:299-304) */
 int lcm_latents_pool8(const void* lat, void* out_f16, int B, int h, int w, void* stream);
 
+/* Live per-launch timing of the MFMA kernels: between begin/end every contraction / attention launch is bracketed by
+ * HIP events on its launch stream (main kernel only).  lcm_profile_end synchronises those events and writes one
+ * "kernel instantiation<TAB>milliseconds" line per launch, in launch order; returns the number of lines. */
+int lcm_profile_begin(int max_launches);
+int lcm_profile_end(char* out, int64_t cap);
 /* profiling aid: hold the stream busy for `usec` (<= 2 s) so queued launches run back to back */
 int lcm_debug_spin(int usec, void* stream);
 

@@ -42,7 +42,10 @@ def _candidates(key, meta, ws_bytes):
                 if s <= units and ntile * s <= 4096 and s * M * N * 4 <= ws_bytes and (meta["halo"] or s <= nk // 2):
                     splits.append(s)
         for s in splits:
-            variants = (-1,) if meta["halo"] else ((1, 2, 4) if bm + bn <= 128 else (1, 2))
+            # the pipeline depth is NOT tuned here: replaying one launch keeps its weights cache-resident, which
+            # hides exactly the latency the deeper variants exist for (in situ every weight byte comes from HBM);
+            # the library's occupancy rule picks it (csrc/igemm.hip launch_cfg)
+            variants = (-1,)
             for v in variants:
                 out.append((bm, bn, s, v))
     return out

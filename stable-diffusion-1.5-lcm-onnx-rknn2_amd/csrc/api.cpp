@@ -62,3 +62,58 @@ extern "C" int lcm_graph_destroy(void* graph_exec) {
     if (graph_exec) hipGraphExecDestroy((hipGraphExec_t)graph_exec);
     return LCM_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Live per-launch timing of the MFMA kernels (bench.py's roofline leg): between lcm_profile_begin and
+// lcm_profile_end every contraction / attention launch is bracketed by two HIP events recorded on its own launch
+// stream -- around the MAIN kernel only (a split-K combine launch is outside the bracket), labelled with the
+// kernel instantiation so the numbers can be checked against rocprofv3's per-kernel averages.
+// ---------------------------------------------------------------------------------------------------------------
+#include <string>
+#include <vector>
+struct ProfEntry { std::string name; hipEvent_t e0, e1; };
+static std::vector<ProfEntry> g_prof;
+static bool g_prof_on = false;
+static size_t g_prof_cap = 0;
+
+extern "C" int lcm_profile_begin(int max_launches) {
+    if (g_prof_on) { lcm_set_error("profile already running"); return LCM_EINVAL; }
+    g_prof.clear();
+    g_prof.reserve(max_launches > 0 ? max_launches : 0);
+    g_prof_cap = max_launches > 0 ? (size_t)max_launches : 0;
+    g_prof_on = true;
+    return LCM_OK;
+}
+
+void lcm_prof_start(const char* name, hipStream_t s) {
+    if (!g_prof_on || g_prof.size() >= g_prof_cap) return;
+    ProfEntry e; e.name = name;
+    if (hipEventCreate(&e.e0) != hipSuccess || hipEventCreate(&e.e1) != hipSuccess) return;
+    (void)hipEventRecord(e.e0, s);
+    g_prof.push_back(e);
+}
+
+void lcm_prof_stop(hipStream_t s) {
+    if (!g_prof_on || g_prof.empty()) return;
+    (void)hipEventRecord(g_prof.back().e1, s);
+}
+
+// writes "name\tmilliseconds\n" per launch into out (NUL terminated); returns the number of launches or <0
+extern "C" int lcm_profile_end(char* out, int64_t cap) {
+    if (!g_prof_on) { lcm_set_error("profile not running"); return LCM_EINVAL; }
+    g_prof_on = false;
+    int64_t pos = 0;
+    int n = 0;
+    for (auto& e : g_prof) {
+        float ms = -1.f;
+        if (hipEventSynchronize(e.e1) == hipSuccess) (void)hipEventElapsedTime(&ms, e.e0, e.e1);
+        (void)hipEventDestroy(e.e0);
+        (void)hipEventDestroy(e.e1);
+        char line[256];
+        const int len = snprintf(line, sizeof(line), "%s\t%.6f\n", e.name.c_str(), ms);
+        if (out && pos + len + 1 < cap) { memcpy(out + pos, line, len); pos += len; ++n; }
+    }
+    if (out && cap > 0) out[pos] = 0;
+    g_prof.clear();
+    return n;
+}

@@ -228,7 +228,11 @@ static int launch_attn(const AttnParams& p, hipStream_t s) {
         attr_set = true;
     }
     dim3 grid((p.Sq + 127) / 128, p.B * p.heads);
+    char nm[32];
+    snprintf(nm, sizeof(nm), "attn_kernel<%d>", D);
+    lcm_prof_start(nm, s);
     hipLaunchKernelGGL((attn_kernel<D>), grid, dim3(256), C::LDS_BYTES, s, p);
+    lcm_prof_stop(s);
     LCM_CHECK_LAUNCH("attention");
     return LCM_OK;
 }

@@ -17,6 +17,8 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 #define LCM_ENODEV (-2)
 
 void lcm_set_error(const char* fmt, ...);
+void lcm_prof_start(const char* name, hipStream_t s);   // no-ops unless lcm_profile_begin() is active
+void lcm_prof_stop(hipStream_t s);
 
 #define LCM_REQUIRE(cond, ...)            \
     do {                                  \

@@ -369,11 +369,19 @@ static void launch_halo(HaloParams& hp, hipStream_t s) {
                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem);
             attr_set = true;
         }
+        char nm[64];
+        snprintf(nm, sizeof(nm), "conv_halo_pipe_kernel<%d, %d, %d, %d>", TH, TW, BN, WS);
+        lcm_prof_start(nm, s);
         hipLaunchKernelGGL((conv_halo_pipe_kernel<TH, TW, BN, WS>), grid, dim3(256), smem, s, hp);
+        lcm_prof_stop(s);
         return;
     }
     constexpr int smem = HROWS_PAD * 128 + BN * 128;
+    char nm[64];
+    snprintf(nm, sizeof(nm), "conv_halo_kernel<%d, %d, %d, %d>", TH, TW, BN, XFORM);
+    lcm_prof_start(nm, s);
     hipLaunchKernelGGL((conv_halo_kernel<TH, TW, BN, XFORM>), grid, dim3(256), smem, s, hp);
+    lcm_prof_stop(s);
 }
 
 // returns 0 when launched, 1 when the shape is not handled here (caller falls back to the row-gather igemm)

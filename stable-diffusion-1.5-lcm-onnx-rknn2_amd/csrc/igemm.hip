@@ -518,7 +518,11 @@ static int launch_v2(IgemmParams& p, dim3 grid, hipStream_t s) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_set = true;
     }
+    char nm[64];
+    snprintf(nm, sizeof(nm), "igemm2_kernel<%d, %d, %d, %d>", BM, BN, MODE, S);
+    lcm_prof_start(nm, s);
     hipLaunchKernelGGL((igemm2_kernel<BM, BN, MODE, S>), grid, dim3(256), smem, s, p);
+    lcm_prof_stop(s);
     return 0;
 }
 
@@ -545,7 +549,11 @@ static int launch_cfg(IgemmParams& p, int batch, int splits, int plan_variant, h
                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem);
             attr_set = true;
         }
+        char nm[64];
+        snprintf(nm, sizeof(nm), "igemm_kernel<%d, %d, %d>", BM, BN, MODE);
+        lcm_prof_start(nm, s);
         hipLaunchKernelGGL((igemm_kernel<BM, BN, MODE>), grid, dim3(256), smem, s, p);
+        lcm_prof_stop(s);
     } else if (variant == 1) {
         launch_v2<BM, BN, MODE, 1>(p, grid, s);
     } else if (variant == 2) {

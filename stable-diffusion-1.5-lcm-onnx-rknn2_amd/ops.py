@@ -24,20 +24,19 @@ PROFILE = None
 
 
 class _Timed:
+    """Launch-order record of the algorithmic work of each MFMA launch; durations come from the library's own
+    event brackets (lcm_profile_begin / lcm_profile_end), matched 1:1 by launch order."""
+
     def __init__(self, kind, tile, flops, bytes_):
         self.rec = None
         if PROFILE is not None:
-            self.rec = dict(kind=kind, tile=tile, flops=float(flops), bytes=float(bytes_),
-                            e0=torch.cuda.Event(enable_timing=True), e1=torch.cuda.Event(enable_timing=True))
+            self.rec = dict(kind=kind, flops=float(flops), bytes=float(bytes_))
 
     def __enter__(self):
-        if self.rec is not None:
-            self.rec["e0"].record()
         return self
 
     def __exit__(self, *a):
         if self.rec is not None:
-            self.rec["e1"].record()
             PROFILE.append(self.rec)
         return False
 
@@ -278,6 +277,23 @@ def set_tuning(target_wgs=0, max_splits=0, min_wgs=0):
 
 def set_kernel_variant(v):
     _lib.check(_lib.load().lcm_set_kernel_variant(int(v)), "lcm_set_kernel_variant")
+
+
+def profile_begin(max_launches=8192):
+    _lib.check(_lib.load().lcm_profile_begin(int(max_launches)), "lcm_profile_begin")
+
+
+def profile_end():
+    """-> list of (kernel instantiation, milliseconds) in launch order."""
+    buf = C.create_string_buffer(1 << 20)
+    n = _lib.load().lcm_profile_end(buf, len(buf))
+    if n < 0:
+        _lib.check(n, "lcm_profile_end")
+    out = []
+    for line in buf.value.decode().splitlines():
+        name, ms = line.rsplit("\t", 1)
+        out.append((name, float(ms)))
+    return out
 
 
 def debug_spin(usec):
