@@ -62,13 +62,45 @@ def _time(fn, reps):
     return e0.elapsed_time(e1) / reps
 
 
+def _cache_path():
+    return os.environ.get("LCM_TUNE_CACHE", "")
+
+
+def _load_cache():
+    import json
+    p = _cache_path()
+    if p and os.path.exists(p):
+        try:
+            with open(p) as f:
+                return {tuple(int(v) for v in k.split(",")): tuple(val) for k, val in json.load(f).items()}
+        except Exception:
+            return {}
+    return {}
+
+
+def _save_cache(cache):
+    import json
+    p = _cache_path()
+    if p:
+        with open(p, "w") as f:
+            json.dump({",".join(str(v) for v in k): list(val) for k, val in cache.items()}, f)
+
+
 def autotune(records, ws_bytes, reps=None, verbose=False):
-    """records: list of (key, meta, replay) from ops.RECORD.  Returns {key: (bm, bn, splits, variant, ms)}."""
+    """records: list of (key, meta, replay) from ops.RECORD.  Returns {key: (bm, bn, splits, variant, ms)}.
+    LCM_TUNE_CACHE=<file> persists the winners (reproducible plans across processes, no tuning launches)."""
     reps = reps or int(os.environ.get("LCM_AUTOTUNE_REPS", "6"))
     seen, chosen = {}, {}
+    cache = _load_cache()
+    dirty = False
     for key, meta, fn in records:
         seen.setdefault(key, (meta, fn))
     for key, (meta, fn) in seen.items():
+        if key in cache:
+            bm, bn, s, v = (int(x) for x in cache[key][:4])
+            ops.plan_set(key[0], key[1], key[2], key[3], key[4], bm, bn, s, v)
+            chosen[key] = (bm, bn, s, v, float(cache[key][4]) if len(cache[key]) > 4 else 0.0)
+            continue
         best = None
         for (bm, bn, s, v) in _candidates(key, meta, ws_bytes):
             ops.plan_set(key[0], key[1], key[2], key[3], key[4], bm, bn, s, v)
@@ -79,7 +111,11 @@ def autotune(records, ws_bytes, reps=None, verbose=False):
                 best = (bm, bn, s, v, ms)
         ops.plan_set(key[0], key[1], key[2], key[3], key[4], *best[:4])
         chosen[key] = best
+        cache[key] = best
+        dirty = True
         if verbose:
             print(f"[autotune] kind{key[0]} M{key[1]} N{key[2]} K{key[3]} aux{key[4]} -> {best[0]}x{best[1]} "
                   f"splits {best[2]} variant {best[3]} {best[4] * 1e3:.1f}us")
+    if dirty:
+        _save_cache(cache)
     return chosen
