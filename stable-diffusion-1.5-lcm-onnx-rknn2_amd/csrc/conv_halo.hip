@@ -370,7 +370,7 @@ static void launch_halo(HaloParams& hp, hipStream_t s) {
             attr_set = true;
         }
         char nm[64];
-        snprintf(nm, sizeof(nm), "conv_halo_pipe_kernel<%d, %d, %d, %d>", TH, TW, BN, WS);
+        snprintf(nm, sizeof(nm), "conv_halo_pipe_kernel<%d, %d, %d, %d>%s", TH, TW, BN, WS, hp.g.splits > 1 ? " +splitk" : "");
         lcm_prof_start(nm, s);
         hipLaunchKernelGGL((conv_halo_pipe_kernel<TH, TW, BN, WS>), grid, dim3(256), smem, s, hp);
         lcm_prof_stop(s);
@@ -378,7 +378,7 @@ static void launch_halo(HaloParams& hp, hipStream_t s) {
     }
     constexpr int smem = HROWS_PAD * 128 + BN * 128;
     char nm[64];
-    snprintf(nm, sizeof(nm), "conv_halo_kernel<%d, %d, %d, %d>", TH, TW, BN, XFORM);
+    snprintf(nm, sizeof(nm), "conv_halo_kernel<%d, %d, %d, %d>%s", TH, TW, BN, XFORM, hp.g.splits > 1 ? " +splitk" : "");
     lcm_prof_start(nm, s);
     hipLaunchKernelGGL((conv_halo_kernel<TH, TW, BN, XFORM>), grid, dim3(256), smem, s, hp);
     lcm_prof_stop(s);

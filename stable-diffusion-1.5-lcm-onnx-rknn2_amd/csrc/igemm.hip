@@ -519,7 +519,7 @@ static int launch_v2(IgemmParams& p, dim3 grid, hipStream_t s) {
         attr_set = true;
     }
     char nm[64];
-    snprintf(nm, sizeof(nm), "igemm2_kernel<%d, %d, %d, %d>", BM, BN, MODE, S);
+    snprintf(nm, sizeof(nm), "igemm2_kernel<%d, %d, %d, %d>%s", BM, BN, MODE, S, p.splits > 1 ? " +splitk" : "");
     lcm_prof_start(nm, s);
     hipLaunchKernelGGL((igemm2_kernel<BM, BN, MODE, S>), grid, dim3(256), smem, s, p);
     lcm_prof_stop(s);
@@ -550,7 +550,7 @@ static int launch_cfg(IgemmParams& p, int batch, int splits, int plan_variant, h
             attr_set = true;
         }
         char nm[64];
-        snprintf(nm, sizeof(nm), "igemm_kernel<%d, %d, %d>", BM, BN, MODE);
+        snprintf(nm, sizeof(nm), "igemm_kernel<%d, %d, %d>%s", BM, BN, MODE, p.splits > 1 ? " +splitk" : "");
         lcm_prof_start(nm, s);
         hipLaunchKernelGGL((igemm_kernel<BM, BN, MODE>), grid, dim3(256), smem, s, p);
         lcm_prof_stop(s);

@@ -217,6 +217,8 @@ def layernorm(x, gamma, beta, out, M, C, eps=1e-5):
 def attention(q, k, v, out, B, heads, Sq, Sk, d, *, ldq, ldk, ldv, ldo, scale=None):
     L = _lib.load()
     scale = d ** -0.5 if scale is None else scale
+    if RECORD is not None:
+        RECORD.append((None, None, lambda: attention(q, k, v, out, B, heads, Sq, Sk, d, ldq=ldq, ldk=ldk, ldv=ldv, ldo=ldo, scale=scale)))
     with _Timed("attention", f"d{d}", 4.0 * B * heads * Sq * Sk * d, 2.0 * B * heads * d * (2 * Sq + 2 * Sk)):
         rc = L.lcm_attention_f16(_p(q), ldq, _p(k), ldk, _p(v), ldv, _p(out), ldo, B, heads, Sq, Sk, d, float(scale), _stream())
     _lib.check(rc, "lcm_attention_f16")

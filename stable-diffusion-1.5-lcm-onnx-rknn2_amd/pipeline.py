@@ -145,7 +145,7 @@ class LcmHipPipeline:
             finally:
                 recs, ops.RECORD = ops.RECORD, None
             self.stream.synchronize()
-            todo = [r for r in recs if r[0] not in self._tuned_keys]
+            todo = [r for r in recs if r[0] is not None and r[0] not in self._tuned_keys]
             res = autotune.autotune(todo, self._splitk_ws.numel() * 4, verbose=verbose)
             self._tuned_keys.update(res.keys())
             self.stream.synchronize()
