@@ -74,7 +74,11 @@ class HipLcmWorker:
                 raise RuntimeError(f"cross_attention_dim={ucfg['cross_attention_dim']}: SDXL UNets are not "
                                    "supported by the SD1.5 HIP worker")                # cuda_worker.py:114-116
             sched = LCMSchedule.from_config_file(os.path.join(ckpt, "scheduler", "scheduler_config.json"))
-            self._encode = ClipPromptEncoder(ckpt, device)
+            if os.path.isdir(os.path.join(ckpt, "tokenizer")) and os.path.isdir(os.path.join(ckpt, "text_encoder")):
+                self._encode = ClipPromptEncoder(ckpt, device)
+            else:
+                print(f"[hip] {ckpt}: no tokenizer/ + text_encoder/ -- using the synthetic prompt encoder")
+                self._encode = SyntheticPromptEncoder(int(ucfg.get("cross_attention_dim", 768)))
         self.pipe = LcmHipPipeline(usd, vsd, ucfg, vcfg, device=device, schedule=sched)
         self.device = device
         self.dtype = torch.float16

@@ -1,0 +1,132 @@
+"""Checkpoint path: a diffusers-layout directory (model_index.json, unet/, vae/,
+scheduler/) round-trips through the loader with the graph-vs-checkpoint shape audit, and the worker factory reads
+cross_attention_dim from it like backends/worker_factory.py:55-67.  Uses a narrow synthetic checkpoint written on the fly."""
+import json
+import os
+
+import pytest
+import torch
+
+
+def _write_ckpt(root, ucfg, vcfg, vae_attn_names=("to_q", "to_k", "to_v", "to_out.0")):
+    from safetensors.torch import save_file
+    from sdlcm_amd import weights
+    from sdlcm_amd.config import unet_config, vae_config
+    os.makedirs(os.path.join(root, "unet"))
+    os.makedirs(os.path.join(root, "vae"))
+    os.makedirs(os.path.join(root, "scheduler"))
+    usd = weights.synthetic_state_dict(weights.unet_param_spec(ucfg), 0)
+    vsd = weights.synthetic_state_dict(weights.vae_param_spec(vcfg), 1)
+    ren = dict(zip(("to_q", "to_k", "to_v", "to_out.0"), vae_attn_names))
+    vsd_disk = {}
+    for k, v in vsd.items():
+        for new, old in ren.items():
+            k = k.replace(f".attentions.0.{new}.", f".attentions.0.{old}.")
+        vsd_disk[k] = v
+    vsd_disk["encoder.conv_in.weight"] = torch.zeros(4, 3, 3, 3, dtype=torch.float16)     # must be ignored
+    save_file(usd, os.path.join(root, "unet", "diffusion_pytorch_model.safetensors"))
+    save_file(vsd_disk, os.path.join(root, "vae", "diffusion_pytorch_model.safetensors"))
+    full_u = unet_config(ucfg)
+    json.dump({"block_out_channels": list(full_u["block_out_channels"]), "cross_attention_dim": full_u["cross_attention_dim"],
+               "attention_head_dim": full_u["attention_head_dim"], "norm_num_groups": full_u["norm_num_groups"],
+               "time_cond_proj_dim": full_u["time_cond_proj_dim"], "layers_per_block": 2, "in_channels": 4, "out_channels": 4,
+               "down_block_types": ["CrossAttnDownBlock2D"] * 3 + ["DownBlock2D"]},
+              open(os.path.join(root, "unet", "config.json"), "w"))
+    full_v = vae_config(vcfg)
+    json.dump({"block_out_channels": list(full_v["block_out_channels"]), "norm_num_groups": full_v["norm_num_groups"],
+               "scaling_factor": 0.18215, "latent_channels": 4, "layers_per_block": 2},
+              open(os.path.join(root, "vae", "config.json"), "w"))
+    json.dump({"_class_name": "StableDiffusionPipeline"}, open(os.path.join(root, "model_index.json"), "w"))
+    json.dump({"_class_name": "PNDMScheduler", "beta_start": 0.00085, "beta_end": 0.012, "beta_schedule": "scaled_linear",
+               "num_train_timesteps": 1000, "skip_prk_steps": True}, open(os.path.join(root, "scheduler", "scheduler_config.json"), "w"))
+    return usd, vsd
+
+
+UCFG = dict(block_out_channels=(64, 128, 128, 128), attention_head_dim=8, cross_attention_dim=768, norm_num_groups=32,
+            time_cond_proj_dim=256)
+VCFG = dict(block_out_channels=(64, 64, 128, 128), norm_num_groups=32)
+
+
+@pytest.mark.parametrize("legacy_names", [False, True])
+def test_diffusers_dir_round_trip(tmp_path, legacy_names):
+    from sdlcm_amd import weights
+    from sdlcm_amd.scheduler import LCMSchedule
+    root = str(tmp_path / "model")
+    names = ("query", "key", "value", "proj_attn") if legacy_names else ("to_q", "to_k", "to_v", "to_out.0")
+    usd, vsd = _write_ckpt(root, UCFG, VCFG, names)
+    lu, lucfg, lv, lvcfg = weights.load_diffusers_dir(root)
+    assert lucfg["block_out_channels"] == (64, 128, 128, 128) and lucfg["time_cond_proj_dim"] == 256
+    assert lucfg["down_attn"] == (True, True, True, False)
+    assert set(lu) == set(usd) and all(torch.equal(lu[k], usd[k]) for k in usd)
+    assert set(lv) == set(vsd) and all(torch.equal(lv[k], vsd[k]) for k in vsd)          # encoder.* dropped, names mapped
+    # LCMScheduler.from_config semantics: foreign scheduler keys are ignored, shared ones kept
+    s = LCMSchedule.from_config_file(os.path.join(root, "scheduler", "scheduler_config.json"))
+    assert list(s.timesteps(4)) == [999, 759, 499, 259]
+
+
+def test_loader_rejects_graph_mismatch(tmp_path):
+    from safetensors.torch import load_file, save_file
+    from sdlcm_amd import weights
+    root = str(tmp_path / "model")
+    _write_ckpt(root, UCFG, VCFG)
+    p = os.path.join(root, "unet", "diffusion_pytorch_model.safetensors")
+    sd = load_file(p)
+    del sd["mid_block.attentions.0.proj_out.weight"]
+    save_file(sd, p)
+    with pytest.raises(RuntimeError, match="checkpoint/graph mismatch at unet 'mid_block.attentions.0.proj_out.weight'"):
+        weights.load_diffusers_dir(root)
+
+
+def test_factory_detects_family_from_checkpoint(tmp_path, monkeypatch):
+    from sdlcm_amd.backends import worker_factory
+    root = str(tmp_path / "model")
+    _write_ckpt(root, UCFG, VCFG)
+    monkeypatch.setenv("MODEL_ROOT", str(tmp_path))
+    monkeypatch.setenv("MODEL", "model")
+    assert worker_factory.detect_worker_type() == "sd15"
+    cfgp = os.path.join(root, "unet", "config.json")
+    j = json.load(open(cfgp))
+    j["cross_attention_dim"] = 2048
+    json.dump(j, open(cfgp, "w"))
+    assert worker_factory.detect_worker_type() == "sdxl"
+    with pytest.raises(RuntimeError, match="SDXL"):
+        worker_factory.create_hip_worker(worker_id=0)
+    j["cross_attention_dim"] = 999
+    json.dump(j, open(cfgp, "w"))
+    with pytest.raises(RuntimeError, match="Unknown cross_attention_dim"):
+        worker_factory.detect_worker_type()
+
+
+@pytest.mark.gpu
+def test_worker_runs_from_checkpoint_directory(tmp_path, monkeypatch):
+    """A (narrow, synthetic) diffusers-layout checkpoint drives the real worker end to end on the MI355X."""
+    from sdlcm_amd.backends import worker_factory
+    from dataclasses import dataclass
+
+    @dataclass
+    class Req:
+        prompt: str = "a lighthouse"
+        size: str = "128x128"
+        num_inference_steps: int = 2
+        guidance_scale: float = 1.0
+        seed: int = 3
+
+    @dataclass
+    class J:
+        req: Req
+
+    root = str(tmp_path / "model")
+    # 2 heads x 64 = head_dim 64 at every level (the attention kernel is instantiated for 40/64/80/160)
+    _write_ckpt(root, dict(UCFG, block_out_channels=(128, 128, 128, 128), attention_head_dim=2),
+                dict(VCFG, block_out_channels=(64, 128, 128, 128)))
+    monkeypatch.setenv("MODEL_ROOT", str(tmp_path))
+    monkeypatch.setenv("MODEL", "model")
+    monkeypatch.delenv("LCM_HIP_SYNTHETIC", raising=False)
+    w = worker_factory.create_hip_worker(worker_id=3)
+    try:
+        png, seed = w.run_job(J(Req()))
+        assert w.worker_id == 3 and seed == 3 and png[:8] == b"\x89PNG\r\n\x1a\n"
+        png2, _, lat = w.run_job_with_latents(J(Req()))
+        assert png2 == png and len(lat) == 512
+    finally:
+        w.close()
