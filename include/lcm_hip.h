@@ -30,6 +30,8 @@ extern "C" {
 
 #define LCM_EPI_NONE 0
 #define LCM_EPI_GEGLU 1   /* out[m][j] = x*gelu(g); weight rows interleaved x/g in blocks of 16 */
+#define LCM_EPI_QUICK_GELU 2  /* x * sigmoid(1.702 x) after bias (CLIPMLP, hidden_act quick_gelu) */
+#define LCM_EPI_GELU 3        /* exact gelu after bias */
 
 const char* lcm_last_error(void);
 int lcm_version(void);
@@ -149,7 +151,13 @@ int lcm_layernorm_f16(const void* x, const void* gamma, const void* beta, void* 
  * d % 8 == 0, d <= 160.  Online softmax in fp32, no S x S matrix in memory.
  */
 int lcm_attention_f16(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* out, int ldo,
-                      int B, int heads, int Sq, int Sk, int d, float scale, void* stream);
+                      int B, int heads, int Sq, int Sk, int d, float scale, int causal, void* stream);
+/* causal != 0: keys after the query are masked (CLIPTextModel's causal attention mask, transformers; the text
+ * encoder call of the pipeline, twin backends/rknnlcm.py:266-367). */
+
+/* ---- CLIPTextEmbeddings: out[b*S+s] = token_embedding[ids[b*S+s]] + position_embedding[s]; ids int32 ---- */
+int lcm_embed_tokens_f16(const void* ids, const void* tok_emb, const void* pos_emb, void* out, int B, int S, int D,
+                         int vocab, void* stream);
 
 /* ---- row softmax in place over [rows][n] fp16 (AutoencoderKL mid-block attention, d=512 single head) ---- */
 int lcm_softmax_rows_f16(void* x, int rows, int n, int ld, void* stream);

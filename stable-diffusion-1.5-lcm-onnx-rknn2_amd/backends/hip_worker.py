@@ -21,7 +21,7 @@ import torch
 
 from ..lib import LcmHipError
 from ..pipeline import LcmHipPipeline
-from ..prompt import ClipPromptEncoder, SyntheticPromptEncoder
+from ..prompt import HipPromptEncoder
 from ..scheduler import LCMSchedule
 from .. import weights as _weights
 
@@ -62,7 +62,7 @@ class HipLcmWorker:
         if synthetic:
             usd, ucfg = _weights.synthetic_unet(), None
             vsd, vcfg = _weights.synthetic_vae(), None
-            self._encode = SyntheticPromptEncoder()
+            ckpt_root = None
             ckpt = "synthetic"
         else:
             ckpt = os.path.join(model_root, model_name)
@@ -74,17 +74,19 @@ class HipLcmWorker:
                 raise RuntimeError(f"cross_attention_dim={ucfg['cross_attention_dim']}: SDXL UNets are not "
                                    "supported by the SD1.5 HIP worker")                # cuda_worker.py:114-116
             sched = LCMSchedule.from_config_file(os.path.join(ckpt, "scheduler", "scheduler_config.json"))
-            if os.path.isdir(os.path.join(ckpt, "tokenizer")) and os.path.isdir(os.path.join(ckpt, "text_encoder")):
-                self._encode = ClipPromptEncoder(ckpt, device)
-            else:
-                print(f"[hip] {ckpt}: no tokenizer/ + text_encoder/ -- using the synthetic prompt encoder")
-                self._encode = SyntheticPromptEncoder(int(ucfg.get("cross_attention_dim", 768)))
+            ckpt_root = ckpt
         self.pipe = LcmHipPipeline(usd, vsd, ucfg, vcfg, device=device, schedule=sched)
+        # CLIP text encoder on the same kernels (checkpoint text_encoder/ when present, else synthetic CLIP-L weights)
+        with torch.cuda.stream(self.pipe.stream):
+            self._encode = HipPromptEncoder(device, ckpt_root)
+        if self._encode.enc.D != self.pipe.unet.ctx_dim:
+            raise RuntimeError(f"text encoder width {self._encode.enc.D} != UNet cross_attention_dim {self.pipe.unet.ctx_dim}")
         self.device = device
         self.dtype = torch.float16
         self._neg = None
         print(f"[hip] worker {worker_id} loaded: {os.path.basename(ckpt)} on {device} dtype=fp16 "
-              f"unet={self.pipe.unet.weight_bytes() / 1e9:.2f}GB vae={self.pipe.vae.weight_bytes() / 1e9:.2f}GB")
+              f"unet={self.pipe.unet.weight_bytes() / 1e9:.2f}GB vae={self.pipe.vae.weight_bytes() / 1e9:.2f}GB "
+              f"clip={self._encode.enc.weight_bytes() / 1e9:.2f}GB ({self._encode.source})")
 
     # ------------------------------------------------------------------------------------------
     def _generate(self, job):
@@ -96,11 +98,12 @@ class HipLcmWorker:
         if level > 0 and getattr(sl, "style", None):
             # LoRA style adapters are a later row; requests run unstyled.
             print(f"[hip] style_lora '{sl.style}' level {level} ignored (LoRA merge not implemented)")
-        pe = self._encode([req.prompt])
         g = float(req.guidance_scale)
         neg = None
-        if g > 1.0 and not self.pipe.unet.has_cond:
-            neg = self._encode([""])
+        with torch.cuda.stream(self.pipe.stream):
+            pe = self._encode([req.prompt])
+            if g > 1.0 and not self.pipe.unet.has_cond:
+                neg = self._encode([""])
         out = self.pipe.generate(pe, [seed], width, height, int(req.num_inference_steps), g, negative_embeds=neg)
         return out, seed
 

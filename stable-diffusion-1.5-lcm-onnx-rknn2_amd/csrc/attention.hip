@@ -21,6 +21,7 @@ struct AttnParams {
     int ldq, ldk, ldv, ldo;
     int B, heads, Sq, Sk;
     float sc;   // scale * log2(e)
+    int causal; // 1: key index > query index is masked (CLIP text encoder); cross/self attention of the UNet: 0
 };
 
 template <int D>
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = t * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    if (key >= p.Sk) sacc[kb][r] = -1.0e30f;
+                    if (key >= p.Sk || (p.causal && key > qrow)) sacc[kb][r] = -1.0e30f;
                 }
         }
         float mt = -1.0e30f;
@@ -193,7 +194,8 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
     };
     const bool ragged = (p.Sk & 63) != 0;
     for (int t = 0; t < ntiles; ++t) {
-        if (ragged && t == ntiles - 1) tile_body(t, std::true_type{});
+        // masked code path: the ragged last tile, and (causal) every tile that reaches past this workgroup's first query
+        if ((ragged && t == ntiles - 1) || (p.causal && t * 64 + 63 > (int)blockIdx.x * 128)) tile_body(t, std::true_type{});
         else tile_body(t, std::false_type{});
     }
 
@@ -238,12 +240,13 @@ static int launch_attn(const AttnParams& p, hipStream_t s) {
 }
 
 extern "C" int lcm_attention_f16(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* out,
-                                 int ldo, int B, int heads, int Sq, int Sk, int d, float scale, void* stream) {
+                                 int ldo, int B, int heads, int Sq, int Sk, int d, float scale, int causal, void* stream) {
     LCM_REQUIRE(Q && K && V && out, "attention: null pointer");
     LCM_REQUIRE(B > 0 && heads > 0 && Sq > 0 && Sk > 0, "attention: bad shape");
     LCM_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0, "attention: misaligned leading dims");
     AttnParams p = {(const half_t*)Q, (const half_t*)K, (const half_t*)V, (half_t*)out, ldq, ldk, ldv, ldo,
-                    B, heads, Sq, Sk, scale * 1.4426950408889634f};
+                    B, heads, Sq, Sk, scale * 1.4426950408889634f, causal ? 1 : 0};
+    LCM_REQUIRE(!causal || Sq == Sk, "attention: causal mask needs Sq == Sk");
     hipStream_t s = (hipStream_t)stream;
     switch (d) {
         case 40: return launch_attn<40>(p, s);

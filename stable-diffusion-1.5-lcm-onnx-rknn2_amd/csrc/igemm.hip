@@ -626,7 +626,7 @@ extern "C" int lcm_gemm_f16(const void* A, int lda, const void* A2, int lda2, in
     if (A2) LCM_REQUIRE(K1 > 0 && K1 < K && K1 % 64 == 0 && lda2 % 8 == 0, "gemm: bad split K1=%d lda2=%d", K1, lda2);
     if (res) LCM_REQUIRE(ldr % 4 == 0, "gemm: ldr=%d misaligned", ldr);
     if (rowadd) LCM_REQUIRE(rows_per_batch > 0 && ld_rowadd % 4 == 0, "gemm: bad rowadd");
-    LCM_REQUIRE(epilogue == 0 || epilogue == 1, "gemm: unknown epilogue %d", epilogue);
+    LCM_REQUIRE(epilogue >= 0 && epilogue <= 3, "gemm: unknown epilogue %d", epilogue);
     if (epilogue == 1) LCM_REQUIRE(!rowadd && !res && !A2, "gemm: GEGLU epilogue takes bias only");
     IgemmParams p = {};
     p.A = (const half_t*)A; p.A2 = (const half_t*)A2; p.W = (const half_t*)W;

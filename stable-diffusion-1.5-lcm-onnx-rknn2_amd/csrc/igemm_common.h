@@ -67,7 +67,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f4 (&acc)[B
         const int m = m_of[b];
         if (m < 0) continue;
         const half_t* radd = p.rowadd ? p.rowadd + (long long)(m / p.rows_per_batch) * p.ld_rowadd : nullptr;
-        if (p.epi == 0) {
+        if (p.epi != 1) {
 #pragma unroll
             for (int a = 0; a < TN; ++a) {
                 const int n = n_wave + a * 16 + fq * 4;
@@ -77,6 +77,13 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f4 (&acc)[B
                 if (radd) { h4 t = *reinterpret_cast<const h4*>(radd + n);
                     v[0] += (float)t[0]; v[1] += (float)t[1]; v[2] += (float)t[2]; v[3] += (float)t[3]; }
                 v[0] *= p.out_scale; v[1] *= p.out_scale; v[2] *= p.out_scale; v[3] *= p.out_scale;
+                if (p.epi == 2) {          // quick_gelu: x * sigmoid(1.702 x)   (CLIP text encoder MLP)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = v[j] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930157f * v[j]));
+                } else if (p.epi == 3) {   // exact gelu
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = gelu_erf_f(v[j]);
+                }
                 if (p.res) { h4 t = *reinterpret_cast<const h4*>(p.res + (long long)m * p.ldr + n);
                     v[0] += (float)t[0]; v[1] += (float)t[1]; v[2] += (float)t[2]; v[3] += (float)t[3]; }
                 h4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};

@@ -338,3 +338,35 @@ extern "C" int lcm_debug_spin(int usec, void* stream) {
     LCM_CHECK_LAUNCH("debug_spin");
     return LCM_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// CLIPTextEmbeddings: out[b*S + s][:] = token_embedding[ids[b*S + s]][:] + position_embedding[s][:]
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_tokens_kernel(const int* __restrict__ ids, const half_t* __restrict__ tok,
+                                                           const half_t* __restrict__ pos, half_t* __restrict__ out,
+                                                           int rows, int S, int D, int vocab) {
+    const int ncc = D >> 3;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < (long long)rows * ncc; i += (long long)gridDim.x * 256) {
+        const int r = (int)(i / ncc), c = (int)(i - (long long)r * ncc) * 8;
+        int id = ids[r];
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+        h8 a = *reinterpret_cast<const h8*>(tok + (long long)id * D + c);
+        h8 b = *reinterpret_cast<const h8*>(pos + (long long)(r % S) * D + c);
+        h8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (half_t)((float)a[j] + (float)b[j]);
+        *reinterpret_cast<h8*>(out + (long long)r * D + c) = o;
+    }
+}
+
+extern "C" int lcm_embed_tokens_f16(const void* ids, const void* tok_emb, const void* pos_emb, void* out, int B, int S,
+                                    int D, int vocab, void* stream) {
+    LCM_REQUIRE(ids && tok_emb && pos_emb && out, "embed_tokens: null pointer");
+    LCM_REQUIRE(B > 0 && S > 0 && D > 0 && D % 8 == 0 && vocab > 0, "embed_tokens: bad shape");
+    const long long total = (long long)B * S * (D / 8);
+    hipLaunchKernelGGL(embed_tokens_kernel, dim3((unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048)), dim3(256), 0,
+                       (hipStream_t)stream, (const int*)ids, (const half_t*)tok_emb, (const half_t*)pos_emb, (half_t*)out, B * S,
+                       S, D, vocab);
+    LCM_CHECK_LAUNCH("embed_tokens");
+    return LCM_OK;
+}

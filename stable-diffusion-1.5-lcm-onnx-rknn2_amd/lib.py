@@ -39,7 +39,8 @@ _SIGS = {
     "lcm_conv3x3_smalln": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "lcm_groupnorm_f16": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp],
     "lcm_layernorm_f16": [_vp, _vp, _vp, _vp, _i, _i, _f, _vp],
-    "lcm_attention_f16": [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp],
+    "lcm_attention_f16": [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp],
+    "lcm_embed_tokens_f16": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "lcm_softmax_rows_f16": [_vp, _i, _i, _i, _vp],
     "lcm_transpose_f16": [_vp, _i, _vp, _i, _i, _i, _i, _i64, _i64, _vp],
     "lcm_linear_smallm_f16": [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp],

@@ -214,13 +214,22 @@ def layernorm(x, gamma, beta, out, M, C, eps=1e-5):
     return out
 
 
-def attention(q, k, v, out, B, heads, Sq, Sk, d, *, ldq, ldk, ldv, ldo, scale=None):
+def embed_tokens(ids, tok_emb, pos_emb, out, B, S, D):
+    L = _lib.load()
+    _lib.check(L.lcm_embed_tokens_f16(_p(ids), _p(tok_emb), _p(pos_emb), _p(out), B, S, D, tok_emb.shape[0], _stream()),
+               "lcm_embed_tokens_f16")
+    return out
+
+
+def attention(q, k, v, out, B, heads, Sq, Sk, d, *, ldq, ldk, ldv, ldo, scale=None, causal=False):
     L = _lib.load()
     scale = d ** -0.5 if scale is None else scale
     if RECORD is not None:
-        RECORD.append((None, None, lambda: attention(q, k, v, out, B, heads, Sq, Sk, d, ldq=ldq, ldk=ldk, ldv=ldv, ldo=ldo, scale=scale)))
+        RECORD.append((None, None, lambda: attention(q, k, v, out, B, heads, Sq, Sk, d, ldq=ldq, ldk=ldk, ldv=ldv, ldo=ldo,
+                                                     scale=scale, causal=causal)))
     with _Timed("attention", f"d{d}", 4.0 * B * heads * Sq * Sk * d, 2.0 * B * heads * d * (2 * Sq + 2 * Sk)):
-        rc = L.lcm_attention_f16(_p(q), ldq, _p(k), ldk, _p(v), ldv, _p(out), ldo, B, heads, Sq, Sk, d, float(scale), _stream())
+        rc = L.lcm_attention_f16(_p(q), ldq, _p(k), ldk, _p(v), ldv, _p(out), ldo, B, heads, Sq, Sk, d, float(scale),
+                                 1 if causal else 0, _stream())
     _lib.check(rc, "lcm_attention_f16")
     return out
 

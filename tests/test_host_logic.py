@@ -37,7 +37,7 @@ def test_abi_argument_validation_without_gpu():
     p = C.cast(buf, C.c_void_p)
     rc = L.lcm_gemm_f16(p, 8, None, 0, 0, p, None, None, 0, 0, None, 0, p, 8, 4, 64, 100, 0, 1.0, 1, 0, 0, 0, None, 0, None, None)
     assert rc == -1 and b"multiple of 64" in L.lcm_last_error()
-    rc = L.lcm_attention_f16(p, 8, p, 8, p, 8, p, 8, 1, 8, 4, 4, 48, 1.0, None)
+    rc = L.lcm_attention_f16(p, 8, p, 8, p, 8, p, 8, 1, 8, 4, 4, 48, 1.0, 0, None)
     assert rc == -1 and b"head_dim" in L.lcm_last_error()
     with pytest.raises(lib.LcmHipError):
         lib.check(rc, "attention")
@@ -133,9 +133,12 @@ def test_png_encoding_is_deterministic_and_lossless():
     assert np.array_equal(np.asarray(Image.open(io.BytesIO(a))), rgb)
 
 
-def test_synthetic_prompt_encoder_is_deterministic():
-    from sdlcm_amd.prompt import SyntheticPromptEncoder
-    e = SyntheticPromptEncoder()
-    a, b, c = e(["a cat"]), e(["a cat"]), e(["a dog"])
-    assert a.shape == (1, 77, 768) and a.dtype == torch.float16
-    assert torch.equal(a, b) and not torch.equal(a, c)
+def test_hash_tokenizer_layout():
+    from sdlcm_amd.clip import HashTokenizer, clip_param_spec
+    from sdlcm_amd import weights
+    t = HashTokenizer()
+    a, b, c = t(["a cat"]), t(["a cat"]), t(["a dog " * 60])
+    assert a.shape == (1, 77) and a.dtype == torch.int32 and torch.equal(a, b)
+    assert a[0, 0] == 49406 and a[0, 3] == 49407 and (a[0, 3:] == 49407).all()          # BOS w1 w2 EOS pad...
+    assert c[0, 0] == 49406 and c[0, 76] == 49407 and c.shape == (1, 77)                 # truncated to 77
+    assert weights.count_params(clip_param_spec()) == 123_060_480                          # CLIP-L text model

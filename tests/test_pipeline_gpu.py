@@ -144,3 +144,19 @@ def test_full_size_parity_512(state):
     b = np.clip(ref["image"] / 2 + 0.5, 0, 1)
     e = _report("512px 4-step image[0,1]", a, b)
     assert e.max() < 1e-2
+
+
+@pytest.mark.parametrize("B,act", [(1, "quick_gelu"), (3, "quick_gelu"), (2, "gelu")])
+def test_clip_text_encoder_parity(B, act):
+    """Native CLIP text encoder (token gather, LN, fused-QKV GEMM, causal flash attention, quick-GELU MLP) against
+    transformers.CLIPTextModel on the CPU in fp32, same (synthetic, CLIP-L sized) weights and token ids."""
+    from sdlcm_amd.clip import CLIP_L, ClipTextHip, HashTokenizer, synthetic_clip
+    from oracle.clip import clip_text_oracle
+    cfg = dict(CLIP_L, hidden_act=act)
+    sd = synthetic_clip(cfg)
+    ids = HashTokenizer()(["a photo of an astronaut riding a horse on mars", "", "x " * 100][:B])
+    ref = clip_text_oracle(sd, cfg, ids).numpy()
+    enc = ClipTextHip(sd, cfg, device="cuda:0")
+    got = enc.forward(ids).float().cpu().numpy()
+    e = _report(f"clip last_hidden_state B={B} {act}", got, ref)
+    assert e.max() < 2e-2 * max(1.0, np.abs(ref).max())
