@@ -43,6 +43,18 @@ def draw_noise(seed: int, h: int, w: int, n_extra: int, sigma: float = 1.0):
     return lat, extra
 
 
+_WS = {}
+
+
+def _splitk_workspace(device):
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    t = _WS.get(key)
+    if t is None:
+        t = torch.empty(int(os.environ.get("LCM_SPLITK_WS_MB", "64")) << 18, dtype=torch.float32, device=device)
+        _WS[key] = t
+    return t
+
+
 class _Plan:
     """Buffers + captured graph for one (B, h, w, steps, cfg) key."""
 
@@ -85,9 +97,10 @@ class LcmHipPipeline:
         self._plans = {}
         self._tuned_keys = set()
         self.stream = torch.cuda.Stream(device=self.device)
-        # fp32 scratch for deterministic split-K of the deep-K / small-M layers (low-res UNet levels at batch 1)
-        self._splitk_ws = torch.empty(int(os.environ.get("LCM_SPLITK_WS_MB", "64")) << 18, dtype=torch.float32,
-                                      device=self.device)
+        # fp32 scratch for deterministic split-K of the deep-K / small-M layers (low-res UNet levels at batch 1).
+        # The library keeps the raw pointer per device, so the tensor is a process-lifetime singleton per device:
+        # it must outlive every pipeline / captured graph that may still launch with it.
+        self._splitk_ws = _splitk_workspace(self.device)
         ops.set_workspace(self._splitk_ws)
         if "LCM_CONV_IMPL" in os.environ:            # A/B switches for kernel work
             ops.set_conv_impl(int(os.environ["LCM_CONV_IMPL"]))
