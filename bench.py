@@ -135,11 +135,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # rehearsal only (one-GPU box): LCM_BENCH_BACKEND=gloo LCM_BENCH_ONE_DEVICE=1 runs N ranks on cuda:0 with CPU
+    # collectives, exercising everything of the N>1 path except RCCL itself
+    backend = os.environ.get("LCM_BENCH_BACKEND", "nccl")
+    if os.environ.get("LCM_BENCH_ONE_DEVICE", "0") == "1":
+        local = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     dev = f"cuda:{local}"
     pipe = LcmHipPipeline(weights.synthetic_unet(), weights.synthetic_vae(), device=dev)
     B, S, n = args.batch, args.size, args.lcm_steps
@@ -154,7 +162,12 @@ def main():
                 allpe.copy_(torch.randn(world * Bx, 77, 768, generator=torch.Generator().manual_seed(1)).half())
             if dist is not None:
                 pipe.stream.synchronize()
-                dist.broadcast(allpe, src=0)          # the one exchange step: 118 KB per prompt over xGMI
+                if backend == "nccl":
+                    dist.broadcast(allpe, src=0)      # the one exchange step: 118 KB per prompt over xGMI
+                else:
+                    host = allpe.cpu()
+                    dist.broadcast(host, src=0)
+                    allpe.copy_(host)
                 torch.cuda.synchronize()
             P.ehs.copy_(allpe[rank * Bx:(rank + 1) * Bx].reshape(Bx * 77, 768))
             for b in range(Bx):
@@ -198,7 +211,7 @@ def main():
     P = prime(B)
     dt, p50 = timed(P, args.steps, args.warmup)
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     images = world * B * args.steps
