@@ -73,6 +73,10 @@ int lcm_set_tuning(int target_wgs, int max_splits, int min_wgs);
 int lcm_plan_set(int kind, int M, int N, int K, int aux, int bm, int bn, int splits, int variant);
 int lcm_plan_clear(void);
 
+/* 1: short-K GEMM launches with more tiles than the chip holds let each workgroup walk several n-tiles with a
+ * continuous LDS-DMA pipeline (no ramp / drain per tile); 0 (default): one tile per workgroup.  Bit-identical. */
+int lcm_set_persist_n(int on);
+
 /* contraction kernel variant: 0 = register-staged double buffer, 2/3/4 = LDS-DMA pipeline with that many stages */
 int lcm_set_kernel_variant(int variant);
 

@@ -171,7 +171,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 template <int BM, int BN, int MODE, int S>
-__global__ __launch_bounds__(256, S == 1 ? 4 : 2) void igemm2_kernel(IgemmParams p) {
+__global__ __launch_bounds__(256, S == 1 ? (BM + BN < 256 ? 4 : 3) : 2) void igemm2_kernel(IgemmParams p) {
     constexpr int RA = BM / 32, RW = BN / 32;
     constexpr int TM = BM / 32, TN = BN / 32;
     constexpr int XBYTES = BM * 128, WBYTES = BN * 128, BUF = XBYTES + WBYTES;
@@ -181,9 +181,12 @@ __global__ __launch_bounds__(256, S == 1 ? 4 : 2) void igemm2_kernel(IgemmParams
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 1, wn = wave >> 1;
-    const int tile = xcd_remap(blockIdx.x, p.mtiles * p.ntiles);
-    const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
-    const int m_base = mt * BM, n_base = nt * BN;
+    // A workgroup walks n_iters consecutive n-tiles of one m-tile; the (n-tile, k-tile) steps are flattened so the
+    // LDS-DMA ring keeps flowing across n-tile boundaries (short-K GEMMs: no pipeline ramp / drain per tile).
+    const int ngroups = p.ntiles / p.n_iters;
+    const int tile = xcd_remap(blockIdx.x, p.mtiles * ngroups);
+    const int mt = tile / ngroups, nt0 = (tile - mt * ngroups) * p.n_iters;
+    const int m_base = mt * BM;
     const int z = blockIdx.z;
 
     const half_t* __restrict__ Ab = p.A + z * p.strideA;
@@ -209,12 +212,17 @@ __global__ __launch_bounds__(256, S == 1 ? 4 : 2) void igemm2_kernel(IgemmParams
             a_b[i] = b; a_y[i] = oy * p.stride - 1; a_x[i] = (rem - oy * p.Wout) * p.stride - 1;
         }
     }
-    const half_t* wptr = Wb + (long long)(n_base + row0) * p.K + schunk;
+    const half_t* wptr = Wb + (long long)row0 * p.K + schunk;
     const int nk_all = p.K >> 6;
     const int kt0 = (int)((long long)blockIdx.y * nk_all / p.splits);
     const int kt1 = (int)((long long)(blockIdx.y + 1) * nk_all / p.splits);
+    const int nkr = kt1 - kt0;
+    const int T = nkr * p.n_iters;
 
-    auto issue_tile = [&](int kt, int buf) {
+    auto issue_tile = [&](int t, int buf) {          // t = flattened (n-tile, k-tile) step
+        const int ni = t / nkr;
+        const int kt = kt0 + (t - ni * nkr);
+        const int n_base_i = (nt0 + ni) * BN;
         char* xs = smem + buf * BUF + wave * 8 * 128;
         char* ws = xs + XBYTES;
         if (MODE == 0) {
@@ -248,7 +256,7 @@ __global__ __launch_bounds__(256, S == 1 ? 4 : 2) void igemm2_kernel(IgemmParams
         }
 #pragma unroll
         for (int i = 0; i < RW; ++i) {
-            const half_t* src = wptr + (long long)(32 * i) * p.K + (kt << 6);
+            const half_t* src = wptr + (long long)(n_base_i + 32 * i) * p.K + (kt << 6);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(ws + i * 32 * 128), 16, 0, 0);
         }
@@ -264,15 +272,15 @@ __global__ __launch_bounds__(256, S == 1 ? 4 : 2) void igemm2_kernel(IgemmParams
 
 #pragma unroll
     for (int s = 0; s < S - 1; ++s)
-        if (kt0 + s < kt1) issue_tile(kt0 + s, s);
+        if (s < T) issue_tile(s, s);
 
-    int buf = 0;
-    for (int kt = kt0; kt < kt1; ++kt) {
-        // tile kt must have landed; up to min(S-2, tiles issued after kt) newer tiles may stay in flight
-        const int newer = kt1 - 1 - kt;
+    int buf = 0, kstep = 0, ni_cur = 0;
+    for (int t = 0; t < T; ++t) {
+        // tile t must have landed; up to min(S-2, tiles issued after t) newer tiles may stay in flight
+        const int newer = T - 1 - t;
         if (S == 1) {   // single LDS buffer: rely on 4-5 co-resident workgroups per CU to cover the load latency
-            if (kt > kt0) __builtin_amdgcn_s_barrier();      // everyone done reading the previous tile
-            issue_tile(kt, 0);
+            if (t > 0) __builtin_amdgcn_s_barrier();      // everyone done reading the previous tile
+            issue_tile(t, 0);
             wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
         } else {
@@ -282,7 +290,7 @@ __global__ __launch_bounds__(256, S == 1 ? 4 : 2) void igemm2_kernel(IgemmParams
             else if (S >= 3 && newer >= 1) wait_vmcnt<(S >= 3 ? 1 : 0) * LPT>();
             else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
-            if (kt + S - 1 < kt1) issue_tile(kt + S - 1, (buf + S - 1) % S);
+            if (t + S - 1 < T) issue_tile(t + S - 1, (buf + S - 1) % S);
         }
 
         const char* xs = smem + buf * BUF + (wm * (BM / 2)) * 128;
@@ -308,14 +316,22 @@ __global__ __launch_bounds__(256, S == 1 ? 4 : 2) void igemm2_kernel(IgemmParams
                     acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[a], xf[b], acc[a][b], 0, 0, 0);
         }
         buf = (buf + 1 == S) ? 0 : buf + 1;
-    }
-    int m_of[TM];
+        if (++kstep == nkr) {          // this n-tile is complete: epilogue while the next tile's loads are in flight
+            kstep = 0;
+            int m_of[TM];
 #pragma unroll
-    for (int b = 0; b < TM; ++b) {
-        const int m = m_base + wm * (BM / 2) + b * 16 + frow;
-        m_of[b] = m < p.M ? m : -1;
+            for (int b = 0; b < TM; ++b) {
+                const int m = m_base + wm * (BM / 2) + b * 16 + frow;
+                m_of[b] = m < p.M ? m : -1;
+            }
+            igemm_epilogue<BM, BN>(p, acc, m_of, (nt0 + ni_cur) * BN + wn * (BN / 2), fq, z, mt * 2 + wm);
+            ++ni_cur;
+#pragma unroll
+            for (int a = 0; a < TN; ++a)
+#pragma unroll
+                for (int b = 0; b < TM; ++b) acc[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
+        }
     }
-    igemm_epilogue<BM, BN>(p, acc, m_of, n_base + wn * (BN / 2), fq, z, mt * 2 + wm);
 }
 
 // Split-K combine: fixed-order sum of the fp32 slabs (bit-reproducible) + the epilogue of the main kernel, and
@@ -526,20 +542,35 @@ static int launch_v2(IgemmParams& p, dim3 grid, hipStream_t s) {
     return 0;
 }
 
+static int g_persist_n = 0;      // 1: short-K GEMM launches let a workgroup walk several n-tiles (persistent-over-N);
+                                 // bit-identical, measured neutral on the UNet shapes (the limit is L2->LDS bytes per FLOP of
+                                 // the 128x64 tile, not the per-tile pipeline ramp), so it stays off
+
+extern "C" int lcm_set_persist_n(int on) { g_persist_n = on ? 1 : 0; return LCM_OK; }
+
 template <int BM, int BN, int MODE>
 static int launch_cfg(IgemmParams& p, int batch, int splits, int plan_variant, hipStream_t s) {
     p.mtiles = (p.M + BM - 1) / BM;
     p.ntiles = p.N / BN;
     p.splits = splits;
-    dim3 grid(p.mtiles * p.ntiles, splits, batch);
+    p.n_iters = 1;
     int variant = g_variant >= 0 ? g_variant : plan_variant;
+    // persistent-over-N: short K (<= 20 k-tiles), several n-tiles, and more tiles than the chip can hold at once
+    if (g_persist_n && MODE == 0 && splits == 1 && batch == 1 && variant != 0 && p.ntiles > 1 && (p.K >> 6) <= 20 &&
+        (long long)p.mtiles * p.ntiles > 512) {
+        int ni = p.ntiles;                                         // largest divisor of ntiles keeping >= 384 workgroups
+        while (ni > 1 && (p.ntiles % ni != 0 || (long long)p.mtiles * (p.ntiles / ni) < 384)) --ni;
+        p.n_iters = ni;
+    }
+    dim3 grid(p.mtiles * (p.ntiles / p.n_iters), splits, batch);
     if (variant == 5) variant = (BM + BN <= 128) ? 4 : -1;      // deep prefetch on the small tile only
     if (variant == 6) variant = (BM + BN <= 128) ? 6 : -1;
     if (variant < 0) {   // auto: enough workgroups for 4 per CU -> single buffer; small tile -> 4-stage prefetch (short-K,
-                         // latency-bound GEMMs); else double buffer
+                         // latency-bound GEMMs); else double buffer.  A persistent-over-N launch needs a real ring.
         const long long wgs = (long long)grid.x * grid.y * grid.z;
-        variant = wgs >= 1024 ? 1 : ((BM + BN <= 128) ? 4 : 2);
+        variant = (wgs >= 1024 && p.n_iters == 1) ? 1 : ((BM + BN <= 128) ? 4 : 2);
     }
+    if (p.n_iters > 1 && variant == 1) variant = 2;
     if (variant == 4 && BM + BN > 192) variant = 3;      // 4 x 32 KiB stages only for the small tiles
     if (variant == 0) {
         const int smem = 2 * (BM + BN) * 128;

@@ -25,6 +25,7 @@ struct IgemmParams {
     float* stats;        // optional fused GroupNorm statistics of the OUTPUT: [slab][N][2] = per-channel (sum, sum of
                          // squares) of the fp16-rounded values each half-tile (or reduce slab) stores; null = off
     int reduce_rows;     // rows per workgroup of splitk_reduce_kernel
+    int n_iters;         // igemm2: consecutive n-tiles one workgroup walks with a continuous LDS-DMA pipeline (>= 1)
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -55,26 +56,25 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f4 (&acc)[B
     }
 
     // ---- epilogue: lane holds out[m = ..+frow][n = ..+fq*4 .. +3] ----
+    // Loop order: n-tile outer, m-tile inner -- bias and the 8 statistics accumulators of one n-tile are the only
+    // values live across the inner loop (keeps the epilogue inside the 128-VGPR budget of the single-buffer variant).
     half_t* __restrict__ outb = p.out + z * p.strideO;
     const bool do_stats = p.stats != nullptr && p.epi == 0;
-    float ssum[TN][4], ssq[TN][4];
+    const int lane = threadIdx.x & 63;
+    if (p.epi != 1) {
 #pragma unroll
-    for (int a = 0; a < TN; ++a)
+        for (int a = 0; a < TN; ++a) {
+            const int n = n_wave + a * 16 + fq * 4;
+            f4 bias4 = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) { h4 t = *reinterpret_cast<const h4*>(p.bias + n); bias4 = (f4){(float)t[0], (float)t[1], (float)t[2], (float)t[3]}; }
+            float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { ssum[a][j] = 0.f; ssq[a][j] = 0.f; }
-#pragma unroll
-    for (int b = 0; b < TM; ++b) {
-        const int m = m_of[b];
-        if (m < 0) continue;
-        const half_t* radd = p.rowadd ? p.rowadd + (long long)(m / p.rows_per_batch) * p.ld_rowadd : nullptr;
-        if (p.epi != 1) {
-#pragma unroll
-            for (int a = 0; a < TN; ++a) {
-                const int n = n_wave + a * 16 + fq * 4;
+            for (int b = 0; b < TM; ++b) {
+                const int m = m_of[b];
+                if (m < 0) continue;
                 f4 v = acc[a][b];
-                if (p.bias) { h4 t = *reinterpret_cast<const h4*>(p.bias + n);
-                    v[0] += (float)t[0]; v[1] += (float)t[1]; v[2] += (float)t[2]; v[3] += (float)t[3]; }
-                if (radd) { h4 t = *reinterpret_cast<const h4*>(radd + n);
+                v[0] += bias4[0]; v[1] += bias4[1]; v[2] += bias4[2]; v[3] += bias4[3];
+                if (p.rowadd) { h4 t = *reinterpret_cast<const h4*>(p.rowadd + (long long)(m / p.rows_per_batch) * p.ld_rowadd + n);
                     v[0] += (float)t[0]; v[1] += (float)t[1]; v[2] += (float)t[2]; v[3] += (float)t[3]; }
                 v[0] *= p.out_scale; v[1] *= p.out_scale; v[2] *= p.out_scale; v[3] *= p.out_scale;
                 if (p.epi == 2) {          // quick_gelu: x * sigmoid(1.702 x)   (CLIP text encoder MLP)
@@ -90,46 +90,47 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f4 (&acc)[B
                 *reinterpret_cast<h4*>(outb + (long long)m * p.ldo + n) = o;
                 if (do_stats) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { const float f = (float)o[j]; ssum[a][j] += f; ssq[a][j] += f * f; }
+                    for (int j = 0; j < 4; ++j) { const float f = (float)o[j]; ssum[j] += f; ssq[j] += f * f; }
                 }
             }
-        } else {  // GEGLU: even n-tile = value rows, odd n-tile = gate rows (16-row interleave)
+            if (do_stats) {   // fold the 16 pixel-lanes of the channel quad; one lane writes (sum, sumsq) x 4
 #pragma unroll
-            for (int a = 0; a < TN; a += 2) {
-                const int n = n_wave + a * 16 + fq * 4;      // packed row of the value
-                f4 x = acc[a][b], g = acc[a + 1][b];
-                if (p.bias) {
-                    h4 tx = *reinterpret_cast<const h4*>(p.bias + n);
-                    h4 tg = *reinterpret_cast<const h4*>(p.bias + n + 16);
+                for (int j = 0; j < 4; ++j) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { x[j] += (float)tx[j]; g[j] += (float)tg[j]; }
+                    for (int o = 1; o < 16; o <<= 1) {
+                        ssum[j] += __shfl_xor(ssum[j], o, 64);
+                        ssq[j] += __shfl_xor(ssq[j], o, 64);
+                    }
                 }
+                if ((lane & 15) == 0) {
+                    float* dst = p.stats + ((long long)stats_slab * p.N + n) * 2;
+                    *reinterpret_cast<f4*>(dst) = (f4){ssum[0], ssq[0], ssum[1], ssq[1]};
+                    *reinterpret_cast<f4*>(dst + 4) = (f4){ssum[2], ssq[2], ssum[3], ssq[3]};
+                }
+            }
+        }
+    } else {  // GEGLU: even n-tile = value rows, odd n-tile = gate rows (16-row interleave)
+#pragma unroll
+        for (int a = 0; a < TN; a += 2) {
+            const int n = n_wave + a * 16 + fq * 4;      // packed row of the value
+            f4 bx = {0.f, 0.f, 0.f, 0.f}, bg = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) {
+                h4 tx = *reinterpret_cast<const h4*>(p.bias + n);
+                h4 tg = *reinterpret_cast<const h4*>(p.bias + n + 16);
+                bx = (f4){(float)tx[0], (float)tx[1], (float)tx[2], (float)tx[3]};
+                bg = (f4){(float)tg[0], (float)tg[1], (float)tg[2], (float)tg[3]};
+            }
+            const int nout = ((n_wave + a * 16) >> 1) + fq * 4;
+#pragma unroll
+            for (int b = 0; b < TM; ++b) {
+                const int m = m_of[b];
+                if (m < 0) continue;
+                f4 x = acc[a][b], g = acc[a + 1][b];
                 h4 o;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = (half_t)(x[j] * gelu_erf_f(g[j]));
-                const int nout = ((n_wave + a * 16) >> 1) + fq * 4;
+                for (int j = 0; j < 4; ++j) o[j] = (half_t)((x[j] + bx[j]) * gelu_erf_f(g[j] + bg[j]));
                 *reinterpret_cast<h4*>(outb + (long long)m * p.ldo + nout) = o;
             }
         }
     }
-    if (do_stats) {   // fold the 16 pixel-lanes of each channel quad, then one lane per quad writes (sum, sumsq) x 4
-        const int lane = threadIdx.x & 63;
-#pragma unroll
-        for (int a = 0; a < TN; ++a) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    ssum[a][j] += __shfl_xor(ssum[a][j], o, 64);
-                    ssq[a][j] += __shfl_xor(ssq[a][j], o, 64);
-                }
-            }
-            if ((lane & 15) == 0) {
-                float* dst = p.stats + ((long long)stats_slab * p.N + n_wave + a * 16 + fq * 4) * 2;
-                *reinterpret_cast<f4*>(dst) = (f4){ssum[a][0], ssq[a][0], ssum[a][1], ssq[a][1]};
-                *reinterpret_cast<f4*>(dst + 4) = (f4){ssum[a][2], ssq[a][2], ssum[a][3], ssq[a][3]};
-            }
-        }
-    }
 }
-

@@ -59,6 +59,7 @@ _SIGS = {
     "lcm_set_tuning": [_i, _i, _i],
     "lcm_set_kernel_variant": [_i],
     "lcm_set_conv_impl": [_i],
+    "lcm_set_persist_n": [_i],
     "lcm_set_halo_pipe_threshold": [_i],
     "lcm_plan_set": [_i] * 9,
     "lcm_plan_clear": [],

@@ -167,6 +167,10 @@ def set_halo_pipe_threshold(wgs):
     _lib.check(_lib.load().lcm_set_halo_pipe_threshold(int(wgs)), "lcm_set_halo_pipe_threshold")
 
 
+def set_persist_n(on):
+    _lib.check(_lib.load().lcm_set_persist_n(1 if on else 0), "lcm_set_persist_n")
+
+
 def set_conv_impl(impl):
     _lib.check(_lib.load().lcm_set_conv_impl(int(impl)), "lcm_set_conv_impl")
 

@@ -104,6 +104,8 @@ class LcmHipPipeline:
         ops.set_workspace(self._splitk_ws)
         if "LCM_CONV_IMPL" in os.environ:            # A/B switches for kernel work
             ops.set_conv_impl(int(os.environ["LCM_CONV_IMPL"]))
+        if "LCM_PERSIST_N" in os.environ:
+            ops.set_persist_n(int(os.environ["LCM_PERSIST_N"]))
         if "LCM_HALO_PIPE" in os.environ:
             ops.set_halo_pipe_threshold(int(os.environ["LCM_HALO_PIPE"]))
         if "LCM_KERNEL_VARIANT" in os.environ:

@@ -331,6 +331,30 @@ def test_contraction_kernel_variants(variant):
         ops.set_workspace(None)
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(32768, 320, 320, 0), (8192, 2560, 320, 1), (16384, 1280, 640, 0), (20000, 960, 320, 0),
+                                       (32768, 320, 1280, 0)])
+def test_gemm_persistent_over_n_is_bit_identical(M, N, K, epi):
+    """Walking several n-tiles per workgroup keeps each tile's K order: results must not change at all."""
+    a, w, b = rnd(M, K, seed=1).to(DEV), rnd(N, K, seed=2, scale=K ** -0.5).to(DEV), rnd(N, seed=3).to(DEV)
+    res = rnd(M, N, seed=4).to(DEV) if epi == 0 else None
+    outs = []
+    try:
+        for on in (0, 1):
+            ops.set_persist_n(on)
+            o = torch.empty(M, N // 2 if epi == 1 else N, dtype=torch.float16, device=DEV)
+            st = ops.Stats(torch.zeros(ops.stats_floats(M, N), dtype=torch.float32, device=DEV)) if epi == 0 else None
+            ops.gemm(a, w, o, bias=b, res=res, epilogue=epi, stats=st, stats_hw=4096 if M % 4096 == 0 else 0)
+            outs.append((o, st.buf.clone() if st is not None else None, st.P if st is not None else 0))
+        torch.cuda.synchronize()
+    finally:
+        ops.set_persist_n(0)
+    assert torch.equal(outs[0][0], outs[1][0])
+    if epi == 0:
+        assert outs[0][2] == outs[1][2] and torch.equal(outs[0][1], outs[1][1])
+        ref = F.linear(a.float().cpu(), w.float().cpu(), b.float().cpu()) + res.float().cpu()
+        close(outs[1][0], ref, what="persistent gemm")
+
+
 def test_gemm_splitk():
     M, N, K = 64, 1280, 5120
     a, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)

@@ -109,8 +109,26 @@ def halo_sweep():
     ops.set_workspace(None)
 
 
+def persist_sweep():
+    gemms = ((32768, 320, 320, 0), (32768, 960, 320, 0), (32768, 2560, 320, 1), (32768, 320, 1280, 0), (8192, 640, 640, 0),
+             (8192, 1920, 640, 0), (8192, 5120, 640, 1), (8192, 640, 2560, 0), (2048, 1280, 1280, 0), (2048, 10240, 1280, 1),
+             (2048, 1280, 5120, 0), (4096, 320, 320, 0), (4096, 2560, 320, 1))
+    for (M, N, K, epi) in gemms:
+        a, w = rnd(M, K), rnd(N, K)
+        o = torch.empty(M, N // 2 if epi else N, device=DEV, dtype=torch.float16)
+        line = f"gemm M{M} N{N} K{K} epi{epi}:"
+        for on in (0, 1):
+            ops.set_persist_n(on)
+            t = timeit(lambda: ops.gemm(a, w, o, epilogue=epi), iters=50)
+            line += f"  persist{on} {t * 1e6:7.1f}us {2.0 * M * N * K / t / 1e12:6.0f}TF"
+        print(line)
+    ops.set_persist_n(0)
+
+
 def main():
     print("device", torch.cuda.get_device_name(0))
+    if len(sys.argv) > 1 and sys.argv[1] == "persist":
+        return persist_sweep()
     if len(sys.argv) > 1 and sys.argv[1] == "halo":
         return halo_sweep()
     if len(sys.argv) > 1 and sys.argv[1] == "splitk":
