@@ -15,8 +15,11 @@ from __future__ import annotations
 
 import io
 import os
+import struct
+import zlib
 from typing import Tuple
 
+import numpy as np
 import torch
 
 from ..lib import LcmHipError
@@ -34,11 +37,34 @@ def parse_size(size) -> Tuple[int, int]:
         raise RuntimeError(f"Invalid size '{size}', expected 'WIDTHxHEIGHT'")     # cuda_worker.py:204-208
 
 
+def _png_chunk(tag: bytes, data: bytes) -> bytes:
+    return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+
 def encode_png(rgb) -> bytes:
-    from PIL import Image
-    buf = io.BytesIO()
-    Image.fromarray(rgb).save(buf, format="PNG", compress_level=int(os.environ.get("LCM_PNG_COMPRESS", "6")))
-    return buf.getvalue()
+    """uint8 [H,W,3] -> PNG file bytes (the reference's ``img.save(buf, format="PNG")``, cuda_worker.py:234-239).
+
+    With the sampler at ~22 ms the PIL encoder (40-70 ms for 512x512) would dominate run_job, so the file is
+    written directly: scanline filter 2 ("Up", one vectorised numpy subtraction) + zlib level LCM_PNG_COMPRESS
+    (default 1) in a single IDAT -- lossless, deterministic, ~4x faster at ~15 % larger files.
+    LCM_PNG_ENCODER=pil restores the PIL path."""
+    if os.environ.get("LCM_PNG_ENCODER", "").lower() == "pil":
+        from PIL import Image
+        buf = io.BytesIO()
+        Image.fromarray(rgb).save(buf, format="PNG", compress_level=int(os.environ.get("LCM_PNG_COMPRESS", "6")))
+        return buf.getvalue()
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+    h, w, c = rgb.shape
+    if c != 3:
+        raise ValueError(f"encode_png expects RGB, got {c} channels")
+    flat = rgb.reshape(h, w * 3)
+    raw = np.empty((h, 1 + w * 3), np.uint8)
+    raw[:, 0] = 2                      # filter type Up
+    raw[0, 1:] = flat[0]
+    np.subtract(flat[1:], flat[:-1], out=raw[1:, 1:])      # uint8 wrap-around == mod 256
+    comp = zlib.compress(raw.tobytes(), int(os.environ.get("LCM_PNG_COMPRESS", "1")))
+    return (b"\x89PNG\r\n\x1a\n" + _png_chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0))
+            + _png_chunk(b"IDAT", comp) + _png_chunk(b"IEND", b""))
 
 
 class HipLcmWorker:

@@ -130,7 +130,17 @@ def test_png_encoding_is_deterministic_and_lossless():
     rgb = np.random.RandomState(0).randint(0, 256, size=(64, 48, 3), dtype=np.uint8)
     a, b = encode_png(rgb), encode_png(rgb)
     assert a == b and a[:8] == b"\x89PNG\r\n\x1a\n"
+    im = Image.open(io.BytesIO(a))
+    im.verify()                                    # chunk CRCs / structure
     assert np.array_equal(np.asarray(Image.open(io.BytesIO(a))), rgb)
+    yy, xx = np.mgrid[0:40, 0:56]
+    smooth = np.stack([xx * 4, yy * 6, (xx + yy) * 2], -1).astype(np.uint8)      # wrap-around rows exercise the Up filter
+    assert np.array_equal(np.asarray(Image.open(io.BytesIO(encode_png(smooth)))), smooth)
+    os.environ["LCM_PNG_ENCODER"] = "pil"
+    try:
+        assert np.array_equal(np.asarray(Image.open(io.BytesIO(encode_png(rgb)))), rgb)
+    finally:
+        del os.environ["LCM_PNG_ENCODER"]
 
 
 def test_hash_tokenizer_layout():

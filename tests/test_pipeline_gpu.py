@@ -97,6 +97,19 @@ def test_end_to_end_parity(state, size, steps, seed):
     assert d8.max() <= 3
 
 
+def test_non_square_768x512_parity(state):
+    """BASELINE config 4 geometry (96-wide latents: levels 96/48/24/12, partial 16-wide patches at the 12-pixel level)."""
+    hip, ora = state["hip"], state["ora"]
+    pe = _embeds(1, seed=3)
+    ref = ora(pe.float(), 768, 512, 2, 1.0, 11)
+    out = hip.generate(pe, [11], 768, 512, 2, 1.0, want_float=True)
+    assert out["rgb"].shape == (1, 512, 768, 3)
+    a = np.clip(out["image"].transpose(0, 3, 1, 2) / 2 + 0.5, 0, 1)
+    b = np.clip(ref["image"] / 2 + 0.5, 0, 1)
+    e = _report("768x512 2-step image[0,1]", a, b)
+    assert e.max() < 1e-2
+
+
 def test_graph_replay_equals_eager_and_is_deterministic(state):
     hip = state["hip"]
     pe = _embeds(1, seed=9)
