@@ -216,7 +216,7 @@ def main():
         dt = float(t.item())
     images = world * B * args.steps
     line = {
-        "metric": "512x512 4-step LCM images/sec", "value": round(images / dt, 3), "unit": "images/s",
+        "metric": f"{S}x{S} {n}-step LCM images/sec", "value": round(images / dt, 3), "unit": "images/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
         "p50_latency_ms": round(p50, 3),

@@ -178,6 +178,7 @@ class LcmHipPipeline:
                  want_float=False, taps=None, latents=None):
         """prompt_embeds: [B,77,ctx] (any float dtype, host or device); seeds: B ints.
         Returns dict(rgb uint8 [B,H,W,3] (host), latents fp32 [B,4,h,w] (host), pool8 fp16 [B,4,8,8] (host))."""
+        torch.cuda.set_device(self.device)        # the pool may call from a thread other than the constructing one
         pe = torch.as_tensor(prompt_embeds)
         B = pe.shape[0]
         if width % 64 or height % 64 or width <= 0 or height <= 0:
