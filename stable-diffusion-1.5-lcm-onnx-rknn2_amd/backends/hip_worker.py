@@ -88,23 +88,29 @@ class HipLcmWorker:
         if synthetic:
             usd, ucfg = _weights.synthetic_unet(), None
             vsd, vcfg = _weights.synthetic_vae(), None
-            ckpt_root = None
+            ckpt_root, clip_sd = None, None
             ckpt = "synthetic"
         else:
             ckpt = os.path.join(model_root, model_name)
-            if not (os.path.isdir(ckpt) and os.path.exists(os.path.join(ckpt, "model_index.json"))):
-                raise RuntimeError(f"{ckpt}: the HIP backend loads diffusers-layout directories "
-                                   "(model_index.json); single-file checkpoints are not supported yet")
-            usd, ucfg, vsd, vcfg = _weights.load_diffusers_dir(ckpt)
+            clip_sd = None
+            if os.path.isdir(ckpt) and os.path.exists(os.path.join(ckpt, "model_index.json")):
+                usd, ucfg, vsd, vcfg = _weights.load_diffusers_dir(ckpt)          # cuda_worker.py:66-77
+                format_name = "diffusers"
+            elif os.path.isfile(ckpt) and ckpt.endswith(".safetensors"):
+                usd, ucfg, vsd, vcfg, clip_sd = _weights.load_single_file(ckpt)   # cuda_worker.py:78-85
+                format_name = "single-file"
+            else:
+                raise RuntimeError(f"{ckpt}: expected a diffusers directory (model_index.json) or a .safetensors file "
+                                   "(.ckpt pickles are not loaded: they execute code)")
             if int(ucfg.get("cross_attention_dim", 768)) not in (768, 1024):
                 raise RuntimeError(f"cross_attention_dim={ucfg['cross_attention_dim']}: SDXL UNets are not "
                                    "supported by the SD1.5 HIP worker")                # cuda_worker.py:114-116
             sched = LCMSchedule.from_config_file(os.path.join(ckpt, "scheduler", "scheduler_config.json"))
-            ckpt_root = ckpt
+            ckpt_root = ckpt if format_name == "diffusers" else None
         self.pipe = LcmHipPipeline(usd, vsd, ucfg, vcfg, device=device, schedule=sched)
         # CLIP text encoder on the same kernels (checkpoint text_encoder/ when present, else synthetic CLIP-L weights)
         with torch.cuda.stream(self.pipe.stream):
-            self._encode = HipPromptEncoder(device, ckpt_root)
+            self._encode = HipPromptEncoder(device, ckpt_root, clip_sd)
         if self._encode.enc.D != self.pipe.unet.ctx_dim:
             raise RuntimeError(f"text encoder width {self._encode.enc.D} != UNet cross_attention_dim {self.pipe.unet.ctx_dim}")
         self.device = device

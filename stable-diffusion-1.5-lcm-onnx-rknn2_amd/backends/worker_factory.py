@@ -16,11 +16,22 @@ def detect_worker_type() -> str:
         raise RuntimeError("MODEL_ROOT environment variable is required")
     if not name:
         raise RuntimeError("MODEL environment variable is required")
-    cfgp = os.path.join(root, name, "unet", "config.json")
-    if not os.path.exists(cfgp):
-        raise RuntimeError(f"Model not found or not a diffusers directory: {os.path.join(root, name)}")
-    with open(cfgp) as f:
-        cad = json.load(f).get("cross_attention_dim")
+    path = os.path.join(root, name)
+    cfgp = os.path.join(path, "unet", "config.json")
+    if os.path.isfile(path) and path.endswith(".safetensors"):
+        # single file: read only the header, as utils/model_detector.py:232-284 does
+        from safetensors import safe_open
+        cad = None
+        with safe_open(path, framework="pt") as f:
+            for k in f.keys():
+                if k.endswith("attn2.to_k.weight"):
+                    cad = f.get_slice(k).get_shape()[1]
+                    break
+    elif os.path.exists(cfgp):
+        with open(cfgp) as f:
+            cad = json.load(f).get("cross_attention_dim")
+    else:
+        raise RuntimeError(f"Model not found: {path}")
     if cad in (2048, 1280):
         return "sdxl"
     if cad in (768, 1024):

@@ -29,9 +29,17 @@ class _BpeTokenizer:
 class HipPromptEncoder:
     """prompts (list[str]) -> fp16 [B, 77, D] on the device, computed by the native CLIP text encoder."""
 
-    def __init__(self, device, ckpt_root: str | None = None):
+    def __init__(self, device, ckpt_root: str | None = None, clip_sd: dict | None = None):
         te = os.path.join(ckpt_root, "text_encoder") if ckpt_root else None
-        if te and os.path.isdir(te):
+        if clip_sd is not None:                      # text encoder carried inside a single-file checkpoint
+            sd = clip_sd
+            cfg = dict(num_hidden_layers=1 + max(int(k.split(".")[2]) for k in sd if k.startswith("encoder.layers.")),
+                       hidden_size=sd["embeddings.token_embedding.weight"].shape[1],
+                       vocab_size=sd["embeddings.token_embedding.weight"].shape[0],
+                       intermediate_size=sd["encoder.layers.0.mlp.fc1.weight"].shape[0],
+                       num_attention_heads=sd["embeddings.token_embedding.weight"].shape[1] // 64)
+            self.source = "single-file"
+        elif te and os.path.isdir(te):
             sd, cfg = load_clip_dir(te)
             self.source = "checkpoint"
         else:

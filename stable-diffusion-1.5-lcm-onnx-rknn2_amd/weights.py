@@ -236,3 +236,124 @@ def load_diffusers_dir(root: str):
         if tuple(vsd[name].shape) != tuple(shape):
             vsd[name] = vsd[name].reshape(shape)   # linear attn stored as 1x1 conv or vice versa
     return usd, ucfg, vsd, vcfg
+
+
+# ---------------------------------------------------------------------------------------
+# single-file (LDM / original Stable Diffusion layout) checkpoints
+# ---------------------------------------------------------------------------------------
+_LDM_RES = {"in_layers.0": "norm1", "in_layers.2": "conv1", "emb_layers.1": "time_emb_proj", "out_layers.0": "norm2",
+            "out_layers.3": "conv2", "skip_connection": "conv_shortcut"}
+
+
+def _ldm_res(rest: str) -> str:
+    for old, new in _LDM_RES.items():
+        if rest.startswith(old + "."):
+            return new + rest[len(old):]
+    raise KeyError(rest)
+
+
+def _ldm_unet_key(k: str, layers_per_block: int = 2, down_attn=(True, True, True, False)):
+    """'model.diffusion_model.' key (prefix stripped) -> diffusers UNet2DConditionModel key (or None to drop).
+    Same correspondence the reference relies on when it calls from_single_file (backends/cuda_worker.py:78-85) and
+    inspects at utils/model_detector.py:232-284."""
+    p = k.split(".")
+    per = layers_per_block + 1
+    if p[0] == "time_embed":
+        return {"0": "time_embedding.linear_1", "2": "time_embedding.linear_2"}[p[1]] + "." + p[2]
+    if p[0] == "input_blocks":
+        i = int(p[1])
+        if i == 0:
+            return "conv_in." + p[3]
+        b, l = (i - 1) // per, (i - 1) % per
+        if l == layers_per_block:
+            return f"down_blocks.{b}.downsamplers.0.conv." + p[-1]          # input_blocks.i.0.op.{weight,bias}
+        if p[2] == "0":
+            return f"down_blocks.{b}.resnets.{l}." + _ldm_res(".".join(p[3:]))
+        return f"down_blocks.{b}.attentions.{l}." + ".".join(p[3:])
+    if p[0] == "middle_block":
+        j = int(p[1])
+        if j == 1:
+            return "mid_block.attentions.0." + ".".join(p[2:])
+        return f"mid_block.resnets.{0 if j == 0 else 1}." + _ldm_res(".".join(p[2:]))
+    if p[0] == "output_blocks":
+        i = int(p[1])
+        b, l = i // per, i % per
+        up_attn = tuple(reversed(down_attn))
+        if p[2] == "0":
+            return f"up_blocks.{b}.resnets.{l}." + _ldm_res(".".join(p[3:]))
+        if p[2] == "1" and up_attn[b] and p[3] != "conv":
+            return f"up_blocks.{b}.attentions.{l}." + ".".join(p[3:])
+        return f"up_blocks.{b}.upsamplers.0.conv." + p[-1]                   # output_blocks.i.{1|2}.conv.*
+    if p[0] == "out":
+        return {"0": "conv_norm_out", "2": "conv_out"}[p[1]] + "." + p[2]
+    return None
+
+
+def _ldm_vae_key(k: str, n_up: int = 4):
+    """'first_stage_model.' key (prefix stripped) -> diffusers AutoencoderKL key (decoder side only)."""
+    if k.startswith("post_quant_conv."):
+        return k
+    if not k.startswith("decoder."):
+        return None
+    p = k.split(".")[1:]
+    ren = {"nin_shortcut": "conv_shortcut"}
+    if p[0] in ("conv_in", "conv_out"):
+        return "decoder." + ".".join(p)
+    if p[0] == "norm_out":
+        return "decoder.conv_norm_out." + p[1]
+    if p[0] == "mid":
+        if p[1].startswith("block_"):
+            return f"decoder.mid_block.resnets.{int(p[1][-1]) - 1}." + ".".join(ren.get(t, t) for t in p[2:])
+        a = {"norm": "group_norm", "q": "to_q", "k": "to_k", "v": "to_v", "proj_out": "to_out.0"}[p[2]]
+        return f"decoder.mid_block.attentions.0.{a}." + p[3]
+    if p[0] == "up":
+        b = n_up - 1 - int(p[1])
+        if p[2] == "block":
+            return f"decoder.up_blocks.{b}.resnets.{p[3]}." + ".".join(ren.get(t, t) for t in p[4:])
+        return f"decoder.up_blocks.{b}.upsamplers.0.conv." + p[-1]
+    return None
+
+
+def load_single_file(path: str):
+    """Original-layout .safetensors checkpoint -> (unet_sd, unet_cfg, vae_sd, vae_cfg, clip_sd | None).
+    Architecture numbers are inferred from tensor shapes, then audited against the graph like the directory loader."""
+    from safetensors.torch import load_file
+    raw = load_file(path)
+    usd, vsd, csd = {}, {}, {}
+    for k, v in raw.items():
+        if k.startswith("model.diffusion_model."):
+            kk = k[len("model.diffusion_model."):]
+            nk = "time_embedding.cond_proj.weight" if "cond_proj" in kk else _ldm_unet_key(kk)
+            if nk:
+                usd[nk] = v.to(torch.float16)
+        elif k.startswith("first_stage_model."):
+            nk = _ldm_vae_key(k[len("first_stage_model."):])
+            if nk:
+                vsd[nk] = v.to(torch.float16)
+        elif k.startswith("cond_stage_model.transformer."):
+            kk = k[len("cond_stage_model.transformer."):]
+            kk = kk[len("text_model."):] if kk.startswith("text_model.") else kk
+            if "position_ids" not in kk:
+                csd[kk] = v.to(torch.float16)
+    if "conv_in.weight" not in usd:
+        raise RuntimeError(f"{path}: no model.diffusion_model.* tensors (not an original-layout SD checkpoint)")
+    boc = (usd["conv_in.weight"].shape[0], usd["down_blocks.1.resnets.0.conv1.weight"].shape[0],
+           usd["down_blocks.2.resnets.0.conv1.weight"].shape[0], usd["down_blocks.3.resnets.0.conv1.weight"].shape[0])
+    ucfg = unet_config(dict(block_out_channels=boc,
+                            cross_attention_dim=usd["down_blocks.0.attentions.0.transformer_blocks.0.attn2.to_k.weight"].shape[1],
+                            time_cond_proj_dim=(usd["time_embedding.cond_proj.weight"].shape[1]
+                                                if "time_embedding.cond_proj.weight" in usd else None)))
+    vboc = (vsd["decoder.up_blocks.3.resnets.0.conv1.weight"].shape[0], vsd["decoder.up_blocks.2.resnets.0.conv1.weight"].shape[0],
+            vsd["decoder.up_blocks.1.resnets.0.conv1.weight"].shape[0], vsd["decoder.conv_in.weight"].shape[0])
+    vcfg = vae_config(dict(block_out_channels=vboc))
+    for name, shape, _ in unet_param_spec(ucfg):
+        if name not in usd:
+            raise RuntimeError(f"checkpoint/graph mismatch at unet '{name}': missing")
+        if tuple(usd[name].shape) != tuple(shape):
+            usd[name] = usd[name].reshape(shape)            # linear stored as 1x1 conv or vice versa
+    for name, shape, _ in vae_param_spec(vcfg):
+        if name not in vsd:
+            raise RuntimeError(f"checkpoint/graph mismatch at vae '{name}': missing")
+        if tuple(vsd[name].shape) != tuple(shape):
+            vsd[name] = vsd[name].reshape(shape)
+    return usd, ucfg, vsd, vcfg, (csd or None)

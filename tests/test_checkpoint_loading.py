@@ -130,3 +130,93 @@ def test_worker_runs_from_checkpoint_directory(tmp_path, monkeypatch):
         assert png2 == png and len(lat) == 512
     finally:
         w.close()
+
+
+def _to_ldm_names(usd, vsd, csd):
+    """Independent inverse of the loader's mapping: diffusers names -> original (LDM) single-file names."""
+    out = {}
+    res = {"norm1": "in_layers.0", "conv1": "in_layers.2", "time_emb_proj": "emb_layers.1", "norm2": "out_layers.0",
+           "conv2": "out_layers.3", "conv_shortcut": "skip_connection"}
+
+    def r(rest):
+        head, tail = rest.split(".", 1)
+        return res[head] + "." + tail
+
+    for k, v in usd.items():
+        p = k.split(".")
+        if p[0] == "conv_in":
+            n = "input_blocks.0.0." + p[1]
+        elif p[0] == "time_embedding":
+            n = "time_embed.cond_proj.weight" if p[1] == "cond_proj" else f"time_embed.{0 if p[1] == 'linear_1' else 2}.{p[2]}"
+        elif p[0] == "down_blocks":
+            b = int(p[1])
+            if p[2] == "downsamplers":
+                n = f"input_blocks.{3 * b + 3}.0.op.{p[-1]}"
+            else:
+                i = 3 * b + 1 + int(p[3])
+                n = f"input_blocks.{i}.0." + r(".".join(p[4:])) if p[2] == "resnets" else f"input_blocks.{i}.1." + ".".join(p[4:])
+        elif p[0] == "mid_block":
+            n = f"middle_block.{2 * int(p[2])}." + r(".".join(p[3:])) if p[1] == "resnets" else "middle_block.1." + ".".join(p[3:])
+        elif p[0] == "up_blocks":
+            b = int(p[1])
+            if p[2] == "upsamplers":
+                n = f"output_blocks.{3 * b + 2}.{1 if b == 0 else 2}.conv.{p[-1]}"
+            else:
+                i = 3 * b + int(p[3])
+                n = f"output_blocks.{i}.0." + r(".".join(p[4:])) if p[2] == "resnets" else f"output_blocks.{i}.1." + ".".join(p[4:])
+        elif p[0] == "conv_norm_out":
+            n = "out.0." + p[1]
+        else:
+            n = "out.2." + p[1]
+        out["model.diffusion_model." + n] = v
+    for k, v in vsd.items():
+        if k.startswith("post_quant_conv."):
+            n = k
+        else:
+            p = k.split(".")[1:]
+            if p[0] in ("conv_in", "conv_out"):
+                n = "decoder." + ".".join(p)
+            elif p[0] == "conv_norm_out":
+                n = "decoder.norm_out." + p[1]
+            elif p[0] == "mid_block" and p[1] == "resnets":
+                n = f"decoder.mid.block_{int(p[2]) + 1}." + ".".join(p[3:]).replace("conv_shortcut", "nin_shortcut")
+            elif p[0] == "mid_block":
+                a = ".".join(p[3:-1])
+                n = "decoder.mid.attn_1." + {"group_norm": "norm", "to_q": "q", "to_k": "k", "to_v": "v", "to_out.0": "proj_out"}[a] + "." + p[-1]
+                if a != "group_norm" and p[-1] == "weight":
+                    v = v.reshape(v.shape[0], v.shape[1], 1, 1)           # LDM stores the attention projections as 1x1 convs
+            elif p[2] == "resnets":
+                n = f"decoder.up.{3 - int(p[1])}.block.{p[3]}." + ".".join(p[4:]).replace("conv_shortcut", "nin_shortcut")
+            else:
+                n = f"decoder.up.{3 - int(p[1])}.upsample.conv.{p[-1]}"
+        out["first_stage_model." + n] = v
+    for k, v in csd.items():
+        out["cond_stage_model.transformer.text_model." + k] = v
+    out["cond_stage_model.transformer.text_model.embeddings.position_ids"] = torch.arange(77).unsqueeze(0)
+    out["first_stage_model.encoder.conv_in.weight"] = torch.zeros(4, 3, 3, 3, dtype=torch.float16)
+    return out
+
+
+def test_single_file_checkpoint_round_trip(tmp_path, monkeypatch):
+    """Original-layout single .safetensors (UNet + VAE + CLIP in one file, the format modes.yaml.example points at):
+    the LDM -> diffusers key mapping must restore every tensor, infer the architecture, and feed the factory."""
+    from safetensors.torch import save_file
+    from sdlcm_amd import weights
+    from sdlcm_amd.clip import synthetic_clip
+    from sdlcm_amd.backends import worker_factory
+    ucfg = dict(UCFG, block_out_channels=(64, 128, 192, 192))
+    usd = weights.synthetic_state_dict(weights.unet_param_spec(ucfg), 0)
+    vsd = weights.synthetic_state_dict(weights.vae_param_spec(VCFG), 1)
+    ccfg = dict(num_hidden_layers=2, hidden_size=128, intermediate_size=256, num_attention_heads=2, vocab_size=1000)
+    csd = synthetic_clip(ccfg)
+    path = str(tmp_path / "model.safetensors")
+    save_file({k: v.contiguous() for k, v in _to_ldm_names(usd, vsd, csd).items()}, path)
+    lu, lucfg, lv, lvcfg, lc = weights.load_single_file(path)
+    assert lucfg["block_out_channels"] == (64, 128, 192, 192) and lucfg["cross_attention_dim"] == 768
+    assert lucfg["time_cond_proj_dim"] == 256 and lvcfg["block_out_channels"] == (64, 64, 128, 128)
+    assert set(lu) == set(usd) and all(torch.equal(lu[k], usd[k]) for k in usd)
+    assert set(lv) == set(vsd) and all(torch.equal(lv[k], vsd[k]) for k in vsd)
+    assert set(lc) == set(csd) and all(torch.equal(lc[k], csd[k]) for k in csd)
+    monkeypatch.setenv("MODEL_ROOT", str(tmp_path))
+    monkeypatch.setenv("MODEL", "model.safetensors")
+    assert worker_factory.detect_worker_type() == "sd15"
