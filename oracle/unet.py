@@ -68,8 +68,15 @@ class UNetOracle:
         self._tap(p, out)
         return out
 
-    def attention(self, p, x, ctx):
-        heads = self.cfg["attention_head_dim"]
+    def _heads(self, level):
+        h = self.cfg["attention_head_dim"]
+        return int(h[level]) if isinstance(h, (tuple, list)) else int(h)
+
+    def _depth(self, level):
+        t = self.cfg.get("transformer_layers_per_block", 1)
+        return int(t[level]) if isinstance(t, (tuple, list)) else int(t)
+
+    def attention(self, p, x, ctx, heads):
         q, k, v = self.lin(p + ".to_q", x), self.lin(p + ".to_k", ctx), self.lin(p + ".to_v", ctx)
         B, S, C = q.shape
         d = C // heads
@@ -80,39 +87,62 @@ class UNetOracle:
         a = a.transpose(1, 2).reshape(B, S, C)
         return self.lin(p + ".to_out.0", a)
 
-    def transformer(self, p, x, ehs):
+    def transformer(self, p, x, ehs, level):
+        """Transformer2DModel: 1x1-conv (SD1.5) or Linear (SDXL, use_linear_projection) projections, `depth` blocks."""
         B, C, H, W = x.shape
+        heads, depth = self._heads(level), self._depth(level)
         res = x
         h = self.gn(p + ".norm", x, 1e-6)
-        h = self.conv(p + ".proj_in", h, padding=0)
-        h = h.permute(0, 2, 3, 1).reshape(B, H * W, C)
-        tb = p + ".transformer_blocks.0"
-        h = self.attention(tb + ".attn1", self.ln(tb + ".norm1", h), self.ln(tb + ".norm1", h)) + h
-        h = self.attention(tb + ".attn2", self.ln(tb + ".norm2", h), ehs) + h
-        n = self.ln(tb + ".norm3", h)
-        g = self.lin(tb + ".ff.net.0.proj", n)
-        a, gate = g.chunk(2, dim=-1)
-        h = self.lin(tb + ".ff.net.2", a * F.gelu(gate)) + h
-        h = h.reshape(B, H, W, C).permute(0, 3, 1, 2)
-        out = self.conv(p + ".proj_out", h, padding=0) + res
+        linear = self._w(p + ".proj_in.weight").ndim == 2
+        if linear:
+            h = h.permute(0, 2, 3, 1).reshape(B, H * W, C)
+            h = self.lin(p + ".proj_in", h)
+        else:
+            h = self.conv(p + ".proj_in", h, padding=0)
+            h = h.permute(0, 2, 3, 1).reshape(B, H * W, C)
+        for k in range(depth):
+            tb = f"{p}.transformer_blocks.{k}"
+            n1 = self.ln(tb + ".norm1", h)
+            h = self.attention(tb + ".attn1", n1, n1, heads) + h
+            h = self.attention(tb + ".attn2", self.ln(tb + ".norm2", h), ehs, heads) + h
+            n = self.ln(tb + ".norm3", h)
+            g = self.lin(tb + ".ff.net.0.proj", n)
+            a, gate = g.chunk(2, dim=-1)
+            h = self.lin(tb + ".ff.net.2", a * F.gelu(gate)) + h
+        if linear:
+            h = self.lin(p + ".proj_out", h)
+            h = h.reshape(B, H, W, C).permute(0, 3, 1, 2)
+            out = h + res
+        else:
+            h = h.reshape(B, H, W, C).permute(0, 3, 1, 2)
+            out = self.conv(p + ".proj_out", h, padding=0) + res
         self._tap(p, out)
         return out
 
-    def time_embed(self, t, timestep_cond):
+    def time_embed(self, t, timestep_cond, added=None):
         ch0 = self.cfg["block_out_channels"][0]
         e = timestep_sinusoid(t, ch0)
         if self.cfg.get("time_cond_proj_dim") and timestep_cond is not None:
             e = e + F.linear(timestep_cond.float(), self._w("time_embedding.cond_proj.weight"))
         e = self.lin("time_embedding.linear_1", e)
-        return self.lin("time_embedding.linear_2", F.silu(e))
+        e = self.lin("time_embedding.linear_2", F.silu(e))
+        if self.cfg.get("addition_time_embed_dim"):
+            # SDXL "text_time": concat(pooled text embeds, sinusoid of the 6 size/crop ids) -> MLP, added to temb
+            text_embeds, time_ids = added
+            B = time_ids.shape[0]
+            tid = timestep_sinusoid(time_ids.reshape(-1), self.cfg["addition_time_embed_dim"]).reshape(B, -1)
+            a = torch.cat([text_embeds.float(), tid], dim=-1)
+            a = self.lin("add_embedding.linear_2", F.silu(self.lin("add_embedding.linear_1", a)))
+            e = e + a
+        return e
 
     # -- forward -------------------------------------------------------------
     @torch.inference_mode()
-    def forward(self, sample, t, ehs, timestep_cond=None):
+    def forward(self, sample, t, ehs, timestep_cond=None, added=None):
         cfg = self.cfg
         B = sample.shape[0]
         t = torch.as_tensor(t).reshape(-1).expand(B) if torch.as_tensor(t).numel() == 1 else torch.as_tensor(t)
-        temb = self.time_embed(t, timestep_cond)
+        temb = self.time_embed(t, timestep_cond, added)
         self._tap("temb", temb)
         x = self.conv("conv_in", sample.float())
         self._tap("conv_in", x)
@@ -123,13 +153,13 @@ class UNetOracle:
             for j in range(cfg["layers_per_block"]):
                 x = self.resnet(f"down_blocks.{i}.resnets.{j}", x, temb)
                 if cfg["down_attn"][i]:
-                    x = self.transformer(f"down_blocks.{i}.attentions.{j}", x, ehs)
+                    x = self.transformer(f"down_blocks.{i}.attentions.{j}", x, ehs, i)
                 skips.append(x)
             if i < nb - 1:
                 x = self.conv(f"down_blocks.{i}.downsamplers.0.conv", x, stride=2)
                 skips.append(x)
         x = self.resnet("mid_block.resnets.0", x, temb)
-        x = self.transformer("mid_block.attentions.0", x, ehs)
+        x = self.transformer("mid_block.attentions.0", x, ehs, nb - 1)
         x = self.resnet("mid_block.resnets.1", x, temb)
         up_attn = tuple(reversed(cfg["down_attn"]))
         for i in range(nb):
@@ -137,7 +167,7 @@ class UNetOracle:
                 x = torch.cat([x, skips.pop()], dim=1)
                 x = self.resnet(f"up_blocks.{i}.resnets.{j}", x, temb)
                 if up_attn[i]:
-                    x = self.transformer(f"up_blocks.{i}.attentions.{j}", x, ehs)
+                    x = self.transformer(f"up_blocks.{i}.attentions.{j}", x, ehs, nb - 1 - i)
             if i < nb - 1:
                 x = F.interpolate(x, scale_factor=2.0, mode="nearest")
                 x = self.conv(f"up_blocks.{i}.upsamplers.0.conv", x)

@@ -14,7 +14,7 @@ from __future__ import annotations
 import torch
 
 from . import ops
-from .config import TEXT_SEQ_LEN, unet_config, vae_config
+from .config import TEXT_SEQ_LEN, depth_at, heads_at, unet_config, vae_config
 from .packing import pack_conv1x1, pack_conv3x3, pack_geglu
 
 
@@ -126,7 +126,6 @@ class UNetHip(_Net):
         super().__init__(device)
         self.cfg = cfg = unet_config(cfg)
         boc = cfg["block_out_channels"]
-        self.heads = cfg["attention_head_dim"]
         self.ctx_dim = cfg["cross_attention_dim"]
         self.temb_dim = boc[0] * 4
         nb = len(boc)
@@ -139,24 +138,30 @@ class UNetHip(_Net):
         self.has_cond = bool(cfg.get("time_cond_proj_dim"))
         if self.has_cond:
             self._put("te.cond.w", sd["time_embedding.cond_proj.weight"])
+        self.has_added = bool(cfg.get("addition_time_embed_dim"))       # SDXL "text_time" embedding
+        if self.has_added:
+            for n in ("linear_1", "linear_2"):
+                self._put(f"add.{n}.w", sd[f"add_embedding.{n}.weight"])
+                self._put(f"add.{n}.b", sd[f"add_embedding.{n}.bias"])
+            self.added_dim = cfg["projection_class_embeddings_input_dim"]
         for i in range(nb):
             for j in range(cfg["layers_per_block"]):
                 self._pack_resnet(sd, f"down_blocks.{i}.resnets.{j}", temb_list)
                 if cfg["down_attn"][i]:
-                    self._pack_transformer(sd, f"down_blocks.{i}.attentions.{j}", kv_list)
+                    self._pack_transformer(sd, f"down_blocks.{i}.attentions.{j}", kv_list, depth_at(cfg, i))
             if i < nb - 1:
                 p = f"down_blocks.{i}.downsamplers.0.conv"
                 self._put(p + ".w", pack_conv3x3(sd[p + ".weight"]))
                 self._put(p + ".b", sd[p + ".bias"])
         self._pack_resnet(sd, "mid_block.resnets.0", temb_list)
-        self._pack_transformer(sd, "mid_block.attentions.0", kv_list)
+        self._pack_transformer(sd, "mid_block.attentions.0", kv_list, depth_at(cfg, nb - 1))
         self._pack_resnet(sd, "mid_block.resnets.1", temb_list)
         up_attn = tuple(reversed(cfg["down_attn"]))
         for i in range(nb):
             for j in range(cfg["layers_per_block"] + 1):
                 self._pack_resnet(sd, f"up_blocks.{i}.resnets.{j}", temb_list)
                 if up_attn[i]:
-                    self._pack_transformer(sd, f"up_blocks.{i}.attentions.{j}", kv_list)
+                    self._pack_transformer(sd, f"up_blocks.{i}.attentions.{j}", kv_list, depth_at(cfg, nb - 1 - i))
             if i < nb - 1:
                 p = f"up_blocks.{i}.upsamplers.0.conv"
                 self._put(p + ".w", pack_conv3x3(sd[p + ".weight"]))
@@ -181,29 +186,30 @@ class UNetHip(_Net):
         self.kv_total = off
         self._put("kv_all.w", torch.cat([torch.cat([wk, wv], 0) for _, wk, wv in kv_list], 0))
 
-    def _pack_transformer(self, sd, p, kv_list):
-        t = p + ".transformer_blocks.0"
+    def _pack_transformer(self, sd, p, kv_list, depth=1):
         self._put(p + ".norm.g", sd[p + ".norm.weight"])
         self._put(p + ".norm.b", sd[p + ".norm.bias"])
-        self._put(p + ".proj_in.w", pack_conv1x1(sd[p + ".proj_in.weight"]))
+        self._put(p + ".proj_in.w", pack_conv1x1(sd[p + ".proj_in.weight"]))      # 1x1 conv (SD1.5) or Linear (SDXL)
         self._put(p + ".proj_in.b", sd[p + ".proj_in.bias"])
         self._put(p + ".proj_out.w", pack_conv1x1(sd[p + ".proj_out.weight"]))
         self._put(p + ".proj_out.b", sd[p + ".proj_out.bias"])
-        for n in ("norm1", "norm2", "norm3"):
-            self._put(f"{p}.{n}.g", sd[f"{t}.{n}.weight"])
-            self._put(f"{p}.{n}.b", sd[f"{t}.{n}.bias"])
-        self._put(p + ".qkv.w", torch.cat([sd[f"{t}.attn1.to_{n}.weight"] for n in "qkv"], 0))
-        self._put(p + ".o1.w", sd[f"{t}.attn1.to_out.0.weight"])
-        self._put(p + ".o1.b", sd[f"{t}.attn1.to_out.0.bias"])
-        self._put(p + ".q2.w", sd[f"{t}.attn2.to_q.weight"])
-        self._put(p + ".o2.w", sd[f"{t}.attn2.to_out.0.weight"])
-        self._put(p + ".o2.b", sd[f"{t}.attn2.to_out.0.bias"])
-        kv_list.append((p, sd[f"{t}.attn2.to_k.weight"], sd[f"{t}.attn2.to_v.weight"]))
-        wp, bp = pack_geglu(sd[f"{t}.ff.net.0.proj.weight"], sd[f"{t}.ff.net.0.proj.bias"])
-        self._put(p + ".ff1.w", wp)
-        self._put(p + ".ff1.b", bp)
-        self._put(p + ".ff2.w", sd[f"{t}.ff.net.2.weight"])
-        self._put(p + ".ff2.b", sd[f"{t}.ff.net.2.bias"])
+        for k in range(depth):
+            t, q = f"{p}.transformer_blocks.{k}", f"{p}.{k}"
+            for n in ("norm1", "norm2", "norm3"):
+                self._put(f"{q}.{n}.g", sd[f"{t}.{n}.weight"])
+                self._put(f"{q}.{n}.b", sd[f"{t}.{n}.bias"])
+            self._put(q + ".qkv.w", torch.cat([sd[f"{t}.attn1.to_{n}.weight"] for n in "qkv"], 0))
+            self._put(q + ".o1.w", sd[f"{t}.attn1.to_out.0.weight"])
+            self._put(q + ".o1.b", sd[f"{t}.attn1.to_out.0.bias"])
+            self._put(q + ".q2.w", sd[f"{t}.attn2.to_q.weight"])
+            self._put(q + ".o2.w", sd[f"{t}.attn2.to_out.0.weight"])
+            self._put(q + ".o2.b", sd[f"{t}.attn2.to_out.0.bias"])
+            kv_list.append((q, sd[f"{t}.attn2.to_k.weight"], sd[f"{t}.attn2.to_v.weight"]))
+            wp, bp = pack_geglu(sd[f"{t}.ff.net.0.proj.weight"], sd[f"{t}.ff.net.0.proj.bias"])
+            self._put(q + ".ff1.w", wp)
+            self._put(q + ".ff1.b", bp)
+            self._put(q + ".ff2.w", sd[f"{t}.ff.net.2.weight"])
+            self._put(q + ".ff2.b", sd[f"{t}.ff.net.2.bias"])
 
     # ---- per request: cross-attention K/V of all 16 layers (depend on the prompt only) -------
     def encode_context(self, ehs, B):
@@ -213,7 +219,16 @@ class UNetHip(_Net):
         return kv
 
     # ---- per step: time embedding MLP + all time_emb_proj (depend on t and guidance only) ----
-    def time_embed(self, t, wemb, B):
+    def encode_added(self, add_in, B):
+        """SDXL: add_in fp16 [B, 2816] = [pooled text embeds | sinusoid(6 size/crop ids)] -> aug_emb [B, temb] (per request)."""
+        w = self.w
+        h = self.buf.get("add_h", B, self.temb_dim)
+        ops.linear_smallm(add_in, w["add.linear_1.w"], h, B, self.temb_dim, self.added_dim, bias=w["add.linear_1.b"], silu_out=True)
+        aug = self.buf.get("add_aug", B, self.temb_dim)
+        ops.linear_smallm(h, w["add.linear_2.w"], aug, B, self.temb_dim, self.temb_dim, bias=w["add.linear_2.b"])
+        return aug
+
+    def time_embed(self, t, wemb, B, aug=None):
         w = self.w
         ch0 = self.cfg["block_out_channels"][0]
         e0 = self.buf.get("te0", B, ch0)
@@ -226,7 +241,7 @@ class UNetHip(_Net):
         h = self.buf.get("te_h", B, self.temb_dim)
         ops.linear_smallm(e1, w["te.linear_1.w"], h, B, self.temb_dim, ch0, bias=w["te.linear_1.b"], silu_out=True)
         temb = self.buf.get("temb", B, self.temb_dim)
-        ops.linear_smallm(h, w["te.linear_2.w"], temb, B, self.temb_dim, self.temb_dim, bias=w["te.linear_2.b"])
+        ops.linear_smallm(h, w["te.linear_2.w"], temb, B, self.temb_dim, self.temb_dim, bias=w["te.linear_2.b"], res=aug)
         ta = self.buf.get("temb_all", B, self.temb_total)
         ops.linear_smallm(temb, w["temb_all.w"], ta, B, self.temb_total, self.temb_dim, bias=w["temb_all.b"], silu_in=True)
         return ta
@@ -236,43 +251,45 @@ class UNetHip(_Net):
         return self.resnet(p, x, C1, Cout, B, H, W, self.cfg["norm_eps"], x2=x2, C2=C2, rowadd=ta[:, off:off + n],
                            out_role=out_role, x_st=x_st, x2_st=x2_st)
 
-    def transformer(self, p, x, C, B, H, W, kv_all, out_role, x_st=None):
-        w, heads = self.w, self.heads
+    def transformer(self, p, x, C, B, H, W, kv_all, out_role, x_st=None, heads=8, depth=1):
+        w = self.w
         HW, M, d = H * W, B * H * W, C // heads
         hn = self.buf.get("gn", M, C)
         self.norm(x, w[p + ".norm.g"], w[p + ".norm.b"], hn, B, HW, C, x_st=x_st, eps=1e-6, silu=False)
         h = self.buf.get("tf_h", M, C)
         ops.gemm(hn, w[p + ".proj_in.w"], h, bias=w[p + ".proj_in.b"])
         n = self.buf.get("tf_ln", M, C)
-        ops.layernorm(h, w[p + ".norm1.g"], w[p + ".norm1.b"], n, M, C)
         qkv = self.buf.get("tf_qkv", M, 3 * C)
-        ops.gemm(n, w[p + ".qkv.w"], qkv)
         a = self.buf.get("tf_attn", M, C)
-        ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], a, B, heads, HW, HW, d, ldq=3 * C, ldk=3 * C,
-                      ldv=3 * C, ldo=C)
-        ops.gemm(a, w[p + ".o1.w"], h, bias=w[p + ".o1.b"], res=h)
-        ops.layernorm(h, w[p + ".norm2.g"], w[p + ".norm2.b"], n, M, C)
         q2 = self.buf.get("tf_q2", M, C)
-        ops.gemm(n, w[p + ".q2.w"], q2)
-        off, _ = self.kv_off[p]
-        ops.attention(q2, kv_all[:, off:off + C], kv_all[:, off + C:off + 2 * C], a, B, heads, HW, TEXT_SEQ_LEN, d,
-                      ldq=C, ldk=self.kv_total, ldv=self.kv_total, ldo=C)
-        ops.gemm(a, w[p + ".o2.w"], h, bias=w[p + ".o2.b"], res=h)
-        ops.layernorm(h, w[p + ".norm3.g"], w[p + ".norm3.b"], n, M, C)
         ff = self.buf.get("tf_ff", M, 4 * C)
-        ops.gemm(n, w[p + ".ff1.w"], ff, bias=w[p + ".ff1.b"], epilogue=1)
-        ops.gemm(ff, w[p + ".ff2.w"], h, bias=w[p + ".ff2.b"], res=h)
+        for k in range(depth):
+            q = f"{p}.{k}"
+            ops.layernorm(h, w[q + ".norm1.g"], w[q + ".norm1.b"], n, M, C)
+            ops.gemm(n, w[q + ".qkv.w"], qkv)
+            ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], a, B, heads, HW, HW, d, ldq=3 * C, ldk=3 * C,
+                          ldv=3 * C, ldo=C)
+            ops.gemm(a, w[q + ".o1.w"], h, bias=w[q + ".o1.b"], res=h)
+            ops.layernorm(h, w[q + ".norm2.g"], w[q + ".norm2.b"], n, M, C)
+            ops.gemm(n, w[q + ".q2.w"], q2)
+            off, _ = self.kv_off[q]
+            ops.attention(q2, kv_all[:, off:off + C], kv_all[:, off + C:off + 2 * C], a, B, heads, HW, TEXT_SEQ_LEN, d,
+                          ldq=C, ldk=self.kv_total, ldv=self.kv_total, ldo=C)
+            ops.gemm(a, w[q + ".o2.w"], h, bias=w[q + ".o2.b"], res=h)
+            ops.layernorm(h, w[q + ".norm3.g"], w[q + ".norm3.b"], n, M, C)
+            ops.gemm(n, w[q + ".ff1.w"], ff, bias=w[q + ".ff1.b"], epilogue=1)
+            ops.gemm(ff, w[q + ".ff2.w"], h, bias=w[q + ".ff2.b"], res=h)
         out = self.buf.get(out_role, M, C)
         out_st = self.stats(out_role, M, C)
         ops.gemm(h, w[p + ".proj_out.w"], out, bias=w[p + ".proj_out.b"], res=x, stats=out_st, stats_hw=HW)
         return out, out_st
 
-    def forward(self, lat, t, kv_all, wemb, B, h, w_, eps_out, taps=None):
-        """lat fp32 [B,4,h,w] -> eps_out fp32 [B,h,w,4] (pixel-major)."""
+    def forward(self, lat, t, kv_all, wemb, B, h, w_, eps_out, taps=None, aug=None):
+        """lat fp32 [B,4,h,w] -> eps_out fp32 [B,h,w,4] (pixel-major).  aug: SDXL additional embedding (encode_added)."""
         cfg, wt = self.cfg, self.w
         boc = cfg["block_out_channels"]
         nb = len(boc)
-        ta = self.time_embed(t, wemb, B)
+        ta = self.time_embed(t, wemb, B, aug)
         H, W = h, w_
         x = self.buf.get("skip0", B * H * W, boc[0])
         ops.conv3x3_c4(lat, wt["conv_in.w"], x, B, H, W, boc[0], bias=wt["conv_in.b"])
@@ -293,7 +310,8 @@ class UNetHip(_Net):
                 tap(p, x, ch, H, W)
                 if attn:
                     p = f"down_blocks.{i}.attentions.{j}"
-                    x, st = self.transformer(p, x, ch, B, H, W, kv_all, f"skip{ns}", x_st=st)
+                    x, st = self.transformer(p, x, ch, B, H, W, kv_all, f"skip{ns}", x_st=st, heads=heads_at(cfg, i),
+                                             depth=depth_at(cfg, i))
                     tap(p, x, ch, H, W)
                 skips.append((x, ch, st))
                 ns += 1
@@ -306,7 +324,8 @@ class UNetHip(_Net):
                 skips.append((x, ch, st))
                 ns += 1
         x, st = self._res("mid_block.resnets.0", x, ch, ch, B, H, W, ta, x_st=st)
-        x, st = self.transformer("mid_block.attentions.0", x, ch, B, H, W, kv_all, "tf_out", x_st=st)
+        x, st = self.transformer("mid_block.attentions.0", x, ch, B, H, W, kv_all, "tf_out", x_st=st,
+                                 heads=heads_at(cfg, nb - 1), depth=depth_at(cfg, nb - 1))
         x, st = self._res("mid_block.resnets.1", x, ch, ch, B, H, W, ta, out_role="cur", x_st=st)
         tap("mid_block.resnets.1", x, ch, H, W)
         rboc = tuple(reversed(boc))
@@ -321,7 +340,8 @@ class UNetHip(_Net):
                 tap(p, x, ch, H, W)
                 if up_attn[i]:
                     p = f"up_blocks.{i}.attentions.{j}"
-                    x, st = self.transformer(p, x, ch, B, H, W, kv_all, "cur", x_st=st)
+                    x, st = self.transformer(p, x, ch, B, H, W, kv_all, "cur", x_st=st, heads=heads_at(cfg, nb - 1 - i),
+                                             depth=depth_at(cfg, nb - 1 - i))
                     tap(p, x, ch, H, W)
             if i < nb - 1:
                 p = f"up_blocks.{i}.upsamplers.0.conv"

@@ -15,7 +15,7 @@ import os
 
 import torch
 
-from .config import unet_config, vae_config
+from .config import depth_at, unet_config, vae_config
 
 # kind: conv (OIHW), lin (out,in), vec (bias / norm affine)
 
@@ -37,26 +37,28 @@ def _resnet(p, cin, cout, temb):
         yield p + ".conv_shortcut.bias", (cout,), "bias"
 
 
-def _transformer(p, c, ctx):
+def _transformer(p, c, ctx, depth=1, linear=False):
+    pshape = (c, c) if linear else (c, c, 1, 1)
     yield p + ".norm.weight", (c,), "gamma"
     yield p + ".norm.bias", (c,), "beta"
-    yield p + ".proj_in.weight", (c, c, 1, 1), "w"
+    yield p + ".proj_in.weight", pshape, "w"
     yield p + ".proj_in.bias", (c,), "bias"
-    t = p + ".transformer_blocks.0"
-    for n in ("norm1", "norm2", "norm3"):
-        yield f"{t}.{n}.weight", (c,), "gamma"
-        yield f"{t}.{n}.bias", (c,), "beta"
-    for a, kdim in (("attn1", c), ("attn2", ctx)):
-        yield f"{t}.{a}.to_q.weight", (c, c), "w"
-        yield f"{t}.{a}.to_k.weight", (c, kdim), "w"
-        yield f"{t}.{a}.to_v.weight", (c, kdim), "w"
-        yield f"{t}.{a}.to_out.0.weight", (c, c), "w_res"
-        yield f"{t}.{a}.to_out.0.bias", (c,), "bias"
-    yield f"{t}.ff.net.0.proj.weight", (8 * c, c), "w"
-    yield f"{t}.ff.net.0.proj.bias", (8 * c,), "bias"
-    yield f"{t}.ff.net.2.weight", (c, 4 * c), "w_res"
-    yield f"{t}.ff.net.2.bias", (c,), "bias"
-    yield p + ".proj_out.weight", (c, c, 1, 1), "w_res"
+    for k in range(depth):
+        t = f"{p}.transformer_blocks.{k}"
+        for n in ("norm1", "norm2", "norm3"):
+            yield f"{t}.{n}.weight", (c,), "gamma"
+            yield f"{t}.{n}.bias", (c,), "beta"
+        for a, kdim in (("attn1", c), ("attn2", ctx)):
+            yield f"{t}.{a}.to_q.weight", (c, c), "w"
+            yield f"{t}.{a}.to_k.weight", (c, kdim), "w"
+            yield f"{t}.{a}.to_v.weight", (c, kdim), "w"
+            yield f"{t}.{a}.to_out.0.weight", (c, c), "w_res"
+            yield f"{t}.{a}.to_out.0.bias", (c,), "bias"
+        yield f"{t}.ff.net.0.proj.weight", (8 * c, c), "w"
+        yield f"{t}.ff.net.0.proj.bias", (8 * c,), "bias"
+        yield f"{t}.ff.net.2.weight", (c, 4 * c), "w_res"
+        yield f"{t}.ff.net.2.bias", (c,), "bias"
+    yield p + ".proj_out.weight", pshape, "w_res"
     yield p + ".proj_out.bias", (c,), "bias"
 
 
@@ -73,7 +75,13 @@ def unet_param_spec(cfg: dict | None = None):
     yield "time_embedding.linear_2.bias", (temb,), "bias"
     if cfg.get("time_cond_proj_dim"):
         yield "time_embedding.cond_proj.weight", (boc[0], cfg["time_cond_proj_dim"]), "w"
+    if cfg.get("addition_time_embed_dim"):
+        yield "add_embedding.linear_1.weight", (temb, cfg["projection_class_embeddings_input_dim"]), "w"
+        yield "add_embedding.linear_1.bias", (temb,), "bias"
+        yield "add_embedding.linear_2.weight", (temb, temb), "w"
+        yield "add_embedding.linear_2.bias", (temb,), "bias"
     nb = len(boc)
+    lin = bool(cfg.get("use_linear_projection"))
     skip_ch = [boc[0]]
     ch = boc[0]
     for i in range(nb):
@@ -81,14 +89,14 @@ def unet_param_spec(cfg: dict | None = None):
             yield from _resnet(f"down_blocks.{i}.resnets.{j}", ch, boc[i], temb)
             ch = boc[i]
             if cfg["down_attn"][i]:
-                yield from _transformer(f"down_blocks.{i}.attentions.{j}", ch, ctx)
+                yield from _transformer(f"down_blocks.{i}.attentions.{j}", ch, ctx, depth_at(cfg, i), lin)
             skip_ch.append(ch)
         if i < nb - 1:
             yield f"down_blocks.{i}.downsamplers.0.conv.weight", (ch, ch, 3, 3), "w"
             yield f"down_blocks.{i}.downsamplers.0.conv.bias", (ch,), "bias"
             skip_ch.append(ch)
     yield from _resnet("mid_block.resnets.0", ch, ch, temb)
-    yield from _transformer("mid_block.attentions.0", ch, ctx)
+    yield from _transformer("mid_block.attentions.0", ch, ctx, depth_at(cfg, nb - 1), lin)
     yield from _resnet("mid_block.resnets.1", ch, ch, temb)
     rboc = tuple(reversed(boc))
     up_attn = tuple(reversed(cfg["down_attn"]))
@@ -98,7 +106,7 @@ def unet_param_spec(cfg: dict | None = None):
             yield from _resnet(f"up_blocks.{i}.resnets.{j}", ch + s, rboc[i], temb)
             ch = rboc[i]
             if up_attn[i]:
-                yield from _transformer(f"up_blocks.{i}.attentions.{j}", ch, ctx)
+                yield from _transformer(f"up_blocks.{i}.attentions.{j}", ch, ctx, depth_at(cfg, nb - 1 - i), lin)
         if i < nb - 1:
             yield f"up_blocks.{i}.upsamplers.0.conv.weight", (ch, ch, 3, 3), "w"
             yield f"up_blocks.{i}.upsamplers.0.conv.bias", (ch,), "bias"

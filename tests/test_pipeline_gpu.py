@@ -173,3 +173,34 @@ def test_clip_text_encoder_parity(B, act):
     got = enc.forward(ids).float().cpu().numpy()
     e = _report(f"clip last_hidden_state B={B} {act}", got, ref)
     assert e.max() < 2e-2 * max(1.0, np.abs(ref).max())
+
+
+def test_sdxl_style_unet_parity():
+    """The SDXL UNet family (row a16): 3 levels, no attention at level 0, transformer depth 1/2/3, 64-wide heads, Linear
+    proj_in/out, "text_time" additional embedding, no time_cond_proj -- narrow widths, HIP executor vs oracle."""
+    from sdlcm_amd import weights
+    from sdlcm_amd.config import SDXL_UNET, unet_config
+    from sdlcm_amd.model import UNetHip
+    from oracle.unet import UNetOracle, timestep_sinusoid
+    cfg = unet_config(dict(SDXL_UNET, block_out_channels=(64, 128, 256), attention_head_dim=(1, 2, 4), cross_attention_dim=128,
+                           transformer_layers_per_block=(1, 2, 3), addition_time_embed_dim=32,
+                           projection_class_embeddings_input_dim=64 + 6 * 32))
+    sd = weights.synthetic_state_dict(weights.unet_param_spec(cfg), 0)
+    B, h, w, t = 2, 16, 24, 499
+    g = torch.Generator().manual_seed(4)
+    lat = torch.randn(B, 4, h, w, generator=g)
+    ehs = torch.randn(B, 77, 128, generator=g).half()
+    pooled = torch.randn(B, 64, generator=g).half()
+    time_ids = torch.tensor([[h * 8, w * 8, 0, 0, h * 8, w * 8]] * B, dtype=torch.float32)
+    ora = UNetOracle(sd, cfg)
+    ref = ora.forward(lat, t, ehs.float(), None, added=(pooled.float(), time_ids)).numpy()
+    dev = torch.device("cuda:0")
+    u = UNetHip(sd, cfg, dev)
+    add_in = torch.cat([pooled.float(), timestep_sinusoid(time_ids.reshape(-1), 32).reshape(B, -1)], -1).half().to(dev)
+    kv = u.encode_context(ehs.reshape(B * 77, 128).to(dev), B)
+    aug = u.encode_added(add_in, B)
+    eps = torch.zeros(B, h, w, 4, dtype=torch.float32, device=dev)
+    u.forward(lat.to(dev), t, kv, None, B, h, w, eps, aug=aug)
+    torch.cuda.synchronize()
+    e = _report("sdxl-style unet eps", eps.cpu().numpy().transpose(0, 3, 1, 2), ref)
+    assert e.max() < 2e-2
