@@ -26,7 +26,7 @@ class LCMPipelineOracle:
 
     @torch.inference_mode()
     def __call__(self, prompt_embeds, width, height, steps, guidance_scale, seed,
-                 negative_embeds=None, return_all=False):
+                 negative_embeds=None, return_all=False, added=None, negative_added=None):
         """prompt_embeds [1,77,768] float; returns dict(image_u8 NHWC, image float NCHW, latents)."""
         pe = torch.as_tensor(np.asarray(prompt_embeds), dtype=torch.float32)
         B = pe.shape[0]
@@ -44,11 +44,17 @@ class LCMPipelineOracle:
         trace = []
         for i, t in enumerate(ts):
             if do_cfg:
-                e2 = self.unet.forward(torch.cat([lat, lat]), int(t), torch.cat([ne, pe]), None)
+                add2 = None
+                if added is not None:
+                    na = negative_added if negative_added is not None else (torch.zeros_like(torch.as_tensor(added[0]).float()), added[1])
+                    add2 = (torch.cat([torch.as_tensor(na[0]).float(), torch.as_tensor(added[0]).float()]),
+                            torch.cat([torch.as_tensor(na[1]).float(), torch.as_tensor(added[1]).float()]))
+                e2 = self.unet.forward(torch.cat([lat, lat]), int(t), torch.cat([ne, pe]), None, added=add2)
                 eu, et = e2.chunk(2)
                 eps = eu + guidance_scale * (et - eu)
             else:
-                eps = self.unet.forward(lat, int(t), pe, cond)
+                a1 = None if added is None else (torch.as_tensor(added[0]).float(), torch.as_tensor(added[1]).float())
+                eps = self.unet.forward(lat, int(t), pe, cond, added=a1)
             lat, den = self.sched.step(eps, i, lat, noises[i] if i < len(noises) else None)
             if return_all:
                 trace.append((eps.clone(), lat.clone()))

@@ -17,6 +17,11 @@ import torch
 from . import ops
 from .config import TEXT_SEQ_LEN
 
+# OpenCLIP ViT-bigG/14 text tower (SDXL text_encoder_2, CLIPTextModelWithProjection): 32 layers, 1280 wide, exact GELU,
+# text_projection 1280 -> 1280 on the pooled (EOS) token.
+CLIP_BIGG = dict(vocab_size=49408, hidden_size=1280, intermediate_size=5120, num_hidden_layers=32, num_attention_heads=20,
+                 max_position_embeddings=77, hidden_act="gelu", layer_norm_eps=1e-5, projection_dim=1280)
+
 CLIP_L = dict(vocab_size=49408, hidden_size=768, intermediate_size=3072, num_hidden_layers=12, num_attention_heads=12,
               max_position_embeddings=77, hidden_act="quick_gelu", layer_norm_eps=1e-5)
 
@@ -41,6 +46,8 @@ def clip_param_spec(cfg=None):
         yield f"{p}.mlp.fc2.bias", (D,), "bias"
     yield "final_layer_norm.weight", (D,), "gamma"
     yield "final_layer_norm.bias", (D,), "beta"
+    if c.get("projection_dim"):
+        yield "text_projection.weight", (c["projection_dim"], D), "w"
 
 
 def synthetic_clip(cfg=None, seed=2):
@@ -65,6 +72,8 @@ def load_clip_dir(d: str):
         if os.path.exists(p):
             sd = {(k[len("text_model."):] if k.startswith("text_model.") else k): v.to(torch.float16)
                   for k, v in load_file(p).items()}
+            if "text_projection.weight" in sd:
+                cfg["projection_dim"] = sd["text_projection.weight"].shape[0]
             return sd, cfg
     raise FileNotFoundError(f"no model*.safetensors under {d}")
 
@@ -90,6 +99,9 @@ class ClipTextHip:
                 self.w[f"{i}.{n}.g"], self.w[f"{i}.{n}.b"] = dev(sd[f"{p}.{t}.weight"]), dev(sd[f"{p}.{t}.bias"])
             self.w[f"{i}.fc1.w"], self.w[f"{i}.fc1.b"] = dev(sd[f"{p}.mlp.fc1.weight"]), dev(sd[f"{p}.mlp.fc1.bias"])
             self.w[f"{i}.fc2.w"], self.w[f"{i}.fc2.b"] = dev(sd[f"{p}.mlp.fc2.weight"]), dev(sd[f"{p}.mlp.fc2.bias"])
+        self.has_proj = "text_projection.weight" in sd
+        if self.has_proj:
+            self.w["proj"] = dev(sd["text_projection.weight"])
         self._buf = {}
 
     def _b(self, name, *shape):
@@ -103,8 +115,12 @@ class ClipTextHip:
         return sum(t.numel() * 2 for t in self.w.values())
 
     @torch.inference_mode()
-    def forward(self, ids: torch.Tensor) -> torch.Tensor:
-        """ids: int [B, S<=77] (host or device) -> fp16 [B, S, D] on the device (last_hidden_state)."""
+    def forward(self, ids: torch.Tensor, output="last", pooled=False):
+        """ids: int [B, S<=77] (host or device).
+        output="last": final_layer_norm(last layer)           -> fp16 [B, S, D]   (SD1.5: last_hidden_state)
+        output="penultimate": hidden_states[-2], no final LN   -> fp16 [B, S, D]   (SDXL, both encoders)
+        pooled=True additionally returns text_projection(final_layer_norm(last layer)[EOS token]) fp16 [B, P]
+        (CLIPTextModelWithProjection.text_embeds; EOS = position of the largest id, as transformers does for CLIP)."""
         B, S = ids.shape
         D, F, H = self.D, self.F, self.heads
         M, d = B * S, D // H
@@ -113,7 +129,11 @@ class ClipTextHip:
         x = self._b("x", M, D)
         ops.embed_tokens(ids_d, w["tok"], w["pos"], x, B, S, D)
         n, qkv, a, h = self._b("n", M, D), self._b("qkv", M, 3 * D), self._b("a", M, D), self._b("h", M, F)
-        for i in range(self.L):
+        pen = None
+        last_needed = self.L if (output == "last" or pooled) else self.L - 1
+        for i in range(last_needed):
+            if output == "penultimate" and i == self.L - 1:
+                pen = x.clone()                                    # hidden_states[-2]: input of the last layer (device copy)
             ops.layernorm(x, w[f"{i}.ln1.g"], w[f"{i}.ln1.b"], n, M, D, self.cfg["layer_norm_eps"])
             ops.gemm(n, w[f"{i}.qkv.w"], qkv, bias=w[f"{i}.qkv.b"])
             ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], a, B, H, S, S, d, ldq=3 * D, ldk=3 * D, ldv=3 * D,
@@ -122,9 +142,28 @@ class ClipTextHip:
             ops.layernorm(x, w[f"{i}.ln2.g"], w[f"{i}.ln2.b"], n, M, D, self.cfg["layer_norm_eps"])
             ops.gemm(n, w[f"{i}.fc1.w"], h, bias=w[f"{i}.fc1.b"], epilogue=self.act)
             ops.gemm(h, w[f"{i}.fc2.w"], x, bias=w[f"{i}.fc2.b"], res=x)
-        out = torch.empty(M, D, dtype=torch.float16, device=self.device)
-        ops.layernorm(x, w["fln.g"], w["fln.b"], out, M, D, self.cfg["layer_norm_eps"])
-        return out.reshape(B, S, D)
+        if output == "penultimate":
+            hidden = (pen if pen is not None else x.clone()).reshape(B, S, D)
+        else:
+            hidden = None
+        fin = None
+        if output == "last" or pooled:
+            fin = torch.empty(M, D, dtype=torch.float16, device=self.device)
+            ops.layernorm(x, w["fln.g"], w["fln.b"], fin, M, D, self.cfg["layer_norm_eps"])
+            if output == "last":
+                hidden = fin.reshape(B, S, D)
+        if not pooled:
+            return hidden
+        if not self.has_proj:
+            raise ValueError("pooled output needs text_projection weights (CLIPTextModelWithProjection)")
+        eos = ids.to("cpu").long().argmax(dim=-1) + torch.arange(B) * S          # row of the EOS token per prompt
+        rows = fin.index_select(0, eos.to(self.device)).contiguous()               # gather = data movement only
+        P = self.w["proj"].shape[0]
+        te = torch.empty(B, P, dtype=torch.float16, device=self.device)
+        for b0 in range(0, B, 16):
+            nb = min(16, B - b0)
+            ops.linear_smallm(rows[b0:b0 + nb], self.w["proj"], te[b0:b0 + nb], nb, P, D)
+        return hidden, te
 
 
 class HashTokenizer:

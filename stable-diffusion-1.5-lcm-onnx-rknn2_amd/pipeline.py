@@ -35,6 +35,14 @@ def guidance_scale_embedding(w: np.ndarray, dim: int) -> np.ndarray:
     return e.astype(np.float32)
 
 
+def sinusoid_host(values: np.ndarray, dim: int) -> np.ndarray:
+    """diffusers Timesteps(dim, flip_sin_to_cos=True, freq_shift=0) of a flat array: [cos | sin] per value (SDXL add_time_proj)."""
+    half = dim // 2
+    f = np.exp(-np.log(10000.0) * np.arange(half, dtype=np.float32) / half)
+    e = np.asarray(values, dtype=np.float32).reshape(-1, 1) * f[None, :]
+    return np.concatenate([np.cos(e), np.sin(e)], axis=1).astype(np.float32)
+
+
 def draw_noise(seed: int, h: int, w: int, n_extra: int, sigma: float = 1.0):
     g = torch.Generator(device="cpu").manual_seed(int(seed))
     shape = (1, 4, h, w)
@@ -65,6 +73,8 @@ class _Plan:
         self.UB = UB
         self.ehs = torch.zeros(UB * TEXT_SEQ_LEN, pipe.unet.ctx_dim, dtype=torch.float16, device=dev)
         self.wemb = torch.zeros(UB, pipe.unet.cfg.get("time_cond_proj_dim") or 8, dtype=torch.float16, device=dev)
+        self.add_in = (torch.zeros(UB, pipe.unet.added_dim, dtype=torch.float16, device=dev)
+                       if pipe.unet.has_added else None)          # SDXL: [pooled text embeds | sinusoid(time ids)]
         self.lat0 = torch.zeros(B, 4, h, w, dtype=torch.float32, device=dev)         # request input
         self.lat = torch.zeros(UB, 4, h, w, dtype=torch.float32, device=dev)          # sampler state
         self.noise = torch.zeros(max(steps - 1, 1), B, 4, h, w, dtype=torch.float32, device=dev)
@@ -122,9 +132,10 @@ class LcmHipPipeline:
         else:
             P.lat.copy_(P.lat0)
         kv = self.unet.encode_context(P.ehs, UB)
+        aug = self.unet.encode_added(P.add_in, UB) if self.unet.has_added else None
         wemb = P.wemb if self.unet.has_cond else None
         for i, t in enumerate(ts):
-            self.unet.forward(P.lat, int(t), kv, wemb, UB, h, w, P.eps, taps=taps if i == 0 else None)
+            self.unet.forward(P.lat, int(t), kv, wemb, UB, h, w, P.eps, taps=taps if i == 0 else None, aug=aug)
             coef, last = self.sched.step_coefficients(ts, i)
             noise = P.noise[min(i, P.noise.shape[0] - 1)]
             if P.do_cfg:   # rows [0,B) = negative prompt, [B,2B) = prompt
@@ -139,8 +150,9 @@ class LcmHipPipeline:
         self.vae.decode(final, B, h, w, P.rgb, img_f32=P.img_f32 if want_float else None, taps=taps)
         return final
 
-    def plan(self, B, h, w, steps, do_cfg=False) -> _Plan:
-        key = (B, h, w, steps, do_cfg)
+    def plan(self, B, h, w, steps, do_cfg=False, guidance=None) -> _Plan:
+        # classifier-free guidance bakes the guidance value into the captured step kernels: one plan per value
+        key = (B, h, w, steps, do_cfg, round(float(guidance), 4) if do_cfg and guidance is not None else None)
         P = self._plans.get(key)
         if P is None:
             P = _Plan(self, B, h, w, steps, do_cfg)
@@ -175,7 +187,7 @@ class LcmHipPipeline:
     # ------------------------------------------------------------------------------------------
     @torch.inference_mode()
     def generate(self, prompt_embeds, seeds, width, height, steps, guidance_scale=1.0, negative_embeds=None,
-                 want_float=False, taps=None, latents=None):
+                 want_float=False, taps=None, latents=None, added=None, negative_added=None):
         """prompt_embeds: [B,77,ctx] (any float dtype, host or device); seeds: B ints.
         Returns dict(rgb uint8 [B,H,W,3] (host), latents fp32 [B,4,h,w] (host), pool8 fp16 [B,4,8,8] (host))."""
         torch.cuda.set_device(self.device)        # the pool may call from a thread other than the constructing one
@@ -189,7 +201,9 @@ class LcmHipPipeline:
         do_cfg = (guidance_scale > 1.0) and not has_cond
         if do_cfg and negative_embeds is None:
             raise LcmHipError("classifier-free guidance needs negative_embeds")
-        P = self.plan(B, h, w, steps, do_cfg)
+        if self.unet.has_added and added is None:
+            raise LcmHipError("this UNet needs added=(pooled_text_embeds [B,P], time_ids [B,6]) (SDXL text_time embedding)")
+        P = self.plan(B, h, w, steps, do_cfg, guidance_scale)
         with torch.cuda.stream(self.stream):
             # ---- host-side request state -> device (outside the graph) ----
             for b, s in enumerate(seeds):
@@ -210,12 +224,25 @@ class LcmHipPipeline:
                 P.ehs[B * TEXT_SEQ_LEN:].copy_(pe16, non_blocking=True)
             else:
                 P.ehs.copy_(pe16, non_blocking=True)
+            if self.unet.has_added:
+                def _add_rows(a):
+                    pooled, tids = a
+                    pooled = torch.as_tensor(pooled).to(torch.float32).reshape(B, -1).cpu()
+                    sin = sinusoid_host(np.asarray(tids, dtype=np.float32).reshape(-1), self.unet.cfg["addition_time_embed_dim"])
+                    return torch.cat([pooled, torch.from_numpy(sin).reshape(B, -1)], dim=1).to(torch.float16)
+                rows = _add_rows(added)
+                if do_cfg:
+                    neg_rows = _add_rows(negative_added if negative_added is not None else (torch.zeros(B, rows.shape[1] - 6 * self.unet.cfg["addition_time_embed_dim"]), added[1]))
+                    P.add_in[:B].copy_(neg_rows, non_blocking=True)
+                    P.add_in[B:].copy_(rows, non_blocking=True)
+                else:
+                    P.add_in.copy_(rows, non_blocking=True)
             if has_cond:
                 gs = np.full((B,), float(guidance_scale) - 1.0, dtype=np.float32)
                 P.wemb.copy_(torch.from_numpy(guidance_scale_embedding(gs, P.wemb.shape[1])).to(torch.float16),
                              non_blocking=True)
             # ---- the sampler: eager once (allocates scratch), then captured + replayed ----
-            eager = (not self.use_graph) or taps is not None or want_float or do_cfg
+            eager = (not self.use_graph) or taps is not None or want_float
             if eager:
                 final = self._enqueue(P, guidance_scale, want_float=want_float, taps=taps)
             else:
@@ -228,7 +255,7 @@ class LcmHipPipeline:
                         self._enqueue(P, guidance_scale)
                     P.graph = g
                 P.graph.launch()
-                final = P.lat
+                final = P.lat[B:] if do_cfg else P.lat
             P.h_rgb.copy_(P.rgb, non_blocking=True)
             P.h_pool8.copy_(P.pool8, non_blocking=True)
             P.h_latout.copy_(final, non_blocking=True)

@@ -204,3 +204,59 @@ def test_sdxl_style_unet_parity():
     torch.cuda.synchronize()
     e = _report("sdxl-style unet eps", eps.cpu().numpy().transpose(0, 3, 1, 2), ref)
     assert e.max() < 2e-2
+
+
+def test_clip_sdxl_outputs_parity():
+    """SDXL text conditioning: hidden_states[-2] of both encoders and the projected pooled embedding of the second
+    (CLIPTextModelWithProjection), vs transformers on the CPU; bigG-shaped encoder at reduced depth (8 layers)."""
+    from sdlcm_amd.clip import CLIP_BIGG, CLIP_L, ClipTextHip, HashTokenizer, synthetic_clip
+    from oracle.clip import clip_text_oracle_sdxl
+    ids = HashTokenizer()(["a watercolor painting of a fox in the snow", ""])
+    for cfg in (dict(CLIP_L, num_hidden_layers=4), dict(CLIP_BIGG, num_hidden_layers=8)):
+        sd = synthetic_clip(cfg, seed=5)
+        ref_h, ref_p = clip_text_oracle_sdxl(sd, cfg, ids)
+        enc = ClipTextHip(sd, cfg, device="cuda:0")
+        if ref_p is None:
+            got_h = enc.forward(ids, output="penultimate")
+        else:
+            got_h, got_p = enc.forward(ids, output="penultimate", pooled=True)
+            e = _report(f"clip text_embeds D={cfg['hidden_size']}", got_p.float().cpu().numpy(), ref_p.numpy())
+            assert e.max() < 2e-2 * max(1.0, np.abs(ref_p.numpy()).max())
+        e = _report(f"clip hidden_states[-2] D={cfg['hidden_size']}", got_h.float().cpu().numpy(), ref_h.numpy())
+        assert e.max() < 2e-2 * max(1.0, np.abs(ref_h.numpy()).max())
+
+
+@pytest.mark.parametrize("guidance", [1.0, 5.0])
+def test_sdxl_style_pipeline_parity(guidance):
+    """SDXL-family sampler end to end (text_time conditioning, classifier-free guidance captured in the graph,
+    VAE scaling 0.13025) on narrow synthetic weights: HIP vs oracle, eager and graph replay."""
+    from sdlcm_amd import weights
+    from sdlcm_amd.config import SDXL_UNET, unet_config, vae_config
+    from sdlcm_amd.pipeline import LcmHipPipeline
+    from oracle.pipeline import LCMPipelineOracle
+    ucfg = unet_config(dict(SDXL_UNET, block_out_channels=(64, 128, 256), attention_head_dim=(1, 2, 4), cross_attention_dim=128,
+                            transformer_layers_per_block=(1, 2, 2), addition_time_embed_dim=32,
+                            projection_class_embeddings_input_dim=64 + 6 * 32))
+    vcfg = vae_config(dict(block_out_channels=(64, 64, 128, 128), scaling_factor=0.13025))
+    usd = weights.synthetic_state_dict(weights.unet_param_spec(ucfg), 0)
+    vsd = weights.synthetic_state_dict(weights.vae_param_spec(vcfg), 1)
+    hip = LcmHipPipeline(usd, vsd, ucfg, vcfg, device="cuda:0")
+    ora = LCMPipelineOracle(usd, vsd, ucfg, vcfg)
+    g = torch.Generator().manual_seed(8)
+    pe = torch.randn(1, 77, 128, generator=g).half()
+    ne = torch.randn(1, 77, 128, generator=g).half()
+    pooled = torch.randn(1, 64, generator=g).half()
+    tids = torch.tensor([[128.0, 192.0, 0, 0, 128.0, 192.0]])
+    kw = dict(added=(pooled, tids), negative_embeds=ne if guidance > 1 else None)
+    ref = ora(pe.float(), 192, 128, 3, guidance, 21, negative_embeds=ne.float() if guidance > 1 else None, added=(pooled.float(), tids))
+    out = hip.generate(pe, [21], 192, 128, 3, guidance, want_float=True, **kw)
+    a = np.clip(out["image"].transpose(0, 3, 1, 2) / 2 + 0.5, 0, 1)
+    b = np.clip(ref["image"] / 2 + 0.5, 0, 1)
+    e = _report(f"sdxl-style pipeline g={guidance} image[0,1]", a, b)
+    assert e.max() < 1e-2
+    g1 = hip.generate(pe, [21], 192, 128, 3, guidance, **kw)
+    g2 = hip.generate(pe, [21], 192, 128, 3, guidance, **kw)
+    assert np.array_equal(g1["rgb"], g2["rgb"])
+    d = np.abs(g1["rgb"].astype(int) - out["rgb"].astype(int))
+    assert d.max() <= 2            # graph (autotuned plans) vs the earlier eager pass: summation order only
+    hip.drop_plans()
