@@ -119,8 +119,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1, help="images per GPU per step (BASELINE configs[1]: 1)")
-    ap.add_argument("--size", type=int, default=512)
-    ap.add_argument("--lcm-steps", type=int, default=4)
+    ap.add_argument("--size", type=int, default=None, help="image side (default 512; 1024 for --model sdxl)")
+    ap.add_argument("--lcm-steps", type=int, default=None, help="sampler steps (default 4; 30 for --model sdxl)")
+    ap.add_argument("--model", choices=("sd15", "sdxl"), default="sd15",
+                    help="sd15 = BASELINE configs[1..3]; sdxl = configs[4] (SDXL-base 1024x1024, 30 steps, guidance 1.0, no CFG)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     args = ap.parse_args()
@@ -149,17 +151,26 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     dev = f"cuda:{local}"
-    pipe = LcmHipPipeline(weights.synthetic_unet(), weights.synthetic_vae(), device=dev)
-    B, S, n = args.batch, args.size, args.lcm_steps
+    if args.model == "sdxl":
+        from sdlcm_amd.config import SDXL_UNET, unet_config, vae_config
+        ucfg, vcfg = unet_config(SDXL_UNET), vae_config(dict(scaling_factor=0.13025, sample_size=1024))
+        pipe = LcmHipPipeline(weights.synthetic_state_dict(weights.unet_param_spec(ucfg), 0),
+                              weights.synthetic_state_dict(weights.vae_param_spec(vcfg), 1), ucfg, vcfg, device=dev)
+    else:
+        pipe = LcmHipPipeline(weights.synthetic_unet(), weights.synthetic_vae(), device=dev)
+    B = args.batch
+    S = args.size or (1024 if args.model == "sdxl" else 512)
+    n = args.lcm_steps or (30 if args.model == "sdxl" else 4)
     h = w = S // 8
+    D = pipe.unet.ctx_dim
 
     def prime(Bx):
         """Fill a plan's resident inputs: embeddings broadcast from rank 0 over RCCL, per-request noise."""
         P = pipe.plan(Bx, h, w, n)
         with torch.cuda.stream(pipe.stream):
-            allpe = torch.empty(world * Bx, 77, 768, dtype=torch.float16, device=dev)
+            allpe = torch.empty(world * Bx, 77, D, dtype=torch.float16, device=dev)
             if rank == 0:
-                allpe.copy_(torch.randn(world * Bx, 77, 768, generator=torch.Generator().manual_seed(1)).half())
+                allpe.copy_(torch.randn(world * Bx, 77, D, generator=torch.Generator().manual_seed(1)).half())
             if dist is not None:
                 pipe.stream.synchronize()
                 if backend == "nccl":
@@ -169,7 +180,12 @@ def main():
                     dist.broadcast(host, src=0)
                     allpe.copy_(host)
                 torch.cuda.synchronize()
-            P.ehs.copy_(allpe[rank * Bx:(rank + 1) * Bx].reshape(Bx * 77, 768))
+            P.ehs.copy_(allpe[rank * Bx:(rank + 1) * Bx].reshape(Bx * 77, D))
+            if pipe.unet.has_added:      # SDXL: pooled text embedding + size/crop ids
+                from sdlcm_amd.pipeline import sinusoid_host
+                pooled = torch.randn(Bx, pipe.unet.added_dim - 6 * 256, generator=torch.Generator().manual_seed(2))
+                tid = torch.from_numpy(sinusoid_host(np.array([S, S, 0, 0, S, S] * Bx, np.float32), 256)).reshape(Bx, -1)
+                P.add_in.copy_(torch.cat([pooled, tid], 1).half())
             for b in range(Bx):
                 l0, extra = draw_noise(1000 + rank * Bx + b, h, w, n - 1)
                 P.lat0[b].copy_(l0[0])
@@ -220,16 +236,20 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
         "p50_latency_ms": round(p50, 3),
-        "config": {"workload": f"SD1.5 LCM {S}x{S}, {n} steps, guidance 1.0, batch {B} per GPU, fp16 (fp32 accumulate), "
-                               "hipGraph replay; seeded synthetic SD1.5-architecture weights",
+        "config": {"workload": f"{'SDXL-base' if args.model == 'sdxl' else 'SD1.5'} LCM {S}x{S}, {n} steps, guidance 1.0 (no CFG), "
+                               f"batch {B} per GPU, fp16 (fp32 accumulate), hipGraph replay; seeded synthetic "
+                               f"{'SDXL' if args.model == 'sdxl' else 'SD1.5'}-architecture weights",
                    "batch_per_gpu": B, "global_batch": world * B, "image": f"{S}x{S}", "lcm_steps": n,
                    "parallelism": f"independent requests x{world} (RCCL broadcast of prompt embeddings only)"},
     }
     if rank == 0 and world == 1:
         line["roofline"] = roofline_leg(pipe, P, 1.0, dt / args.steps * 1e3)
-        fl_img = 5.74e12 * (S * S) / (512 * 512) * n / 4
+        if args.model == "sdxl":
+            fl_img = (6.761e12 * n + 10.470e12) * (S * S) / (1024 * 1024)
+        else:
+            fl_img = 5.74e12 * (S * S) / (512 * 512) * n / 4
         line["pipeline_tflops"] = round(fl_img * B / (dt / args.steps) / 1e12, 1)
-        if not args.no_extra and B == 1:
+        if not args.no_extra and B == 1 and args.model == "sd15":
             P8 = prime(8)
             dt8, p508 = timed(P8, max(3, args.steps // 4), 1)
             k8 = max(3, args.steps // 4)

@@ -68,11 +68,15 @@ def encode_png(rgb) -> bytes:
 
 
 class HipLcmWorker:
+    """SD1.5-family worker (drop-in for DiffusersCudaWorker, backends/cuda_worker.py:20-304)."""
+
+    FAMILY = "sd15"
+
     def __init__(self, worker_id: int):
         self.worker_id = worker_id
         model_root = (os.environ.get("MODEL_ROOT") or "").strip()
         model_name = (os.environ.get("MODEL") or "").strip()
-        synthetic = model_name == "synthetic" or os.environ.get("LCM_HIP_SYNTHETIC", "0").lower() in ("1", "true", "yes", "on")
+        synthetic = model_name.startswith("synthetic") or os.environ.get("LCM_HIP_SYNTHETIC", "0").lower() in ("1", "true", "yes", "on")
         if not synthetic:
             if not model_root:
                 raise RuntimeError("MODEL_ROOT is required for BACKEND=hip")
@@ -85,40 +89,55 @@ class HipLcmWorker:
         if not torch.cuda.is_available():
             raise LcmHipError("HipLcmWorker needs an MI355X; no CPU fallback exists on this path")
         sched = LCMSchedule()
+        clip_sd = None
         if synthetic:
-            usd, ucfg = _weights.synthetic_unet(), None
-            vsd, vcfg = _weights.synthetic_vae(), None
-            ckpt_root, clip_sd = None, None
-            ckpt = "synthetic"
+            usd, ucfg, vsd, vcfg = self._synthetic_weights()
+            ckpt_root, ckpt, format_name = None, "synthetic", "synthetic"
         else:
             ckpt = os.path.join(model_root, model_name)
-            clip_sd = None
             if os.path.isdir(ckpt) and os.path.exists(os.path.join(ckpt, "model_index.json")):
                 usd, ucfg, vsd, vcfg = _weights.load_diffusers_dir(ckpt)          # cuda_worker.py:66-77
                 format_name = "diffusers"
-            elif os.path.isfile(ckpt) and ckpt.endswith(".safetensors"):
+            elif os.path.isfile(ckpt) and ckpt.endswith(".safetensors") and self.FAMILY == "sd15":
                 usd, ucfg, vsd, vcfg, clip_sd = _weights.load_single_file(ckpt)   # cuda_worker.py:78-85
                 format_name = "single-file"
             else:
-                raise RuntimeError(f"{ckpt}: expected a diffusers directory (model_index.json) or a .safetensors file "
-                                   "(.ckpt pickles are not loaded: they execute code)")
-            if int(ucfg.get("cross_attention_dim", 768)) not in (768, 1024):
-                raise RuntimeError(f"cross_attention_dim={ucfg['cross_attention_dim']}: SDXL UNets are not "
-                                   "supported by the SD1.5 HIP worker")                # cuda_worker.py:114-116
+                raise RuntimeError(f"{ckpt}: expected a diffusers directory (model_index.json)"
+                                   + (" or a .safetensors file" if self.FAMILY == "sd15" else "")
+                                   + " (.ckpt pickles are not loaded: they execute code)")
+            cad = int(ucfg.get("cross_attention_dim", 768))
+            if (cad in (2048, 1280)) != (self.FAMILY == "sdxl"):
+                raise RuntimeError(f"Loaded UNet with cross_attention_dim={cad} into the {self.FAMILY} worker "
+                                   "(SD1.5: 768/1024, SDXL: 2048)")                  # cuda_worker.py:114-116
             sched = LCMSchedule.from_config_file(os.path.join(ckpt, "scheduler", "scheduler_config.json"))
             ckpt_root = ckpt if format_name == "diffusers" else None
         self.pipe = LcmHipPipeline(usd, vsd, ucfg, vcfg, device=device, schedule=sched)
-        # CLIP text encoder on the same kernels (checkpoint text_encoder/ when present, else synthetic CLIP-L weights)
         with torch.cuda.stream(self.pipe.stream):
-            self._encode = HipPromptEncoder(device, ckpt_root, clip_sd)
-        if self._encode.enc.D != self.pipe.unet.ctx_dim:
-            raise RuntimeError(f"text encoder width {self._encode.enc.D} != UNet cross_attention_dim {self.pipe.unet.ctx_dim}")
+            self._load_text_encoders(device, ckpt_root, clip_sd)
         self.device = device
         self.dtype = torch.float16
-        self._neg = None
-        print(f"[hip] worker {worker_id} loaded: {os.path.basename(ckpt)} on {device} dtype=fp16 "
+        print(f"[hip] worker {worker_id} ({self.FAMILY}) loaded: {os.path.basename(ckpt)} ({format_name}) on {device} dtype=fp16 "
               f"unet={self.pipe.unet.weight_bytes() / 1e9:.2f}GB vae={self.pipe.vae.weight_bytes() / 1e9:.2f}GB "
-              f"clip={self._encode.enc.weight_bytes() / 1e9:.2f}GB ({self._encode.source})")
+              f"text={self._text_bytes() / 1e9:.2f}GB")
+
+    # ---- family hooks -----------------------------------------------------------------------
+    def _synthetic_weights(self):
+        return _weights.synthetic_unet(), None, _weights.synthetic_vae(), None
+
+    def _load_text_encoders(self, device, ckpt_root, clip_sd):
+        # CLIP text encoder on the same kernels (checkpoint text_encoder/ when present, else synthetic CLIP-L weights)
+        self._encode = HipPromptEncoder(device, ckpt_root, clip_sd)
+        if self._encode.enc.D != self.pipe.unet.ctx_dim:
+            raise RuntimeError(f"text encoder width {self._encode.enc.D} != UNet cross_attention_dim {self.pipe.unet.ctx_dim}")
+
+    def _text_bytes(self):
+        return self._encode.enc.weight_bytes()
+
+    def _conditioning(self, req, width, height, guidance):
+        """-> kwargs for LcmHipPipeline.generate (prompt_embeds first)."""
+        pe = self._encode([req.prompt])
+        neg = self._encode([""]) if (guidance > 1.0 and not self.pipe.unet.has_cond) else None
+        return pe, dict(negative_embeds=neg)
 
     # ------------------------------------------------------------------------------------------
     def _generate(self, job):
@@ -131,12 +150,9 @@ class HipLcmWorker:
             # LoRA style adapters are a later row; requests run unstyled.
             print(f"[hip] style_lora '{sl.style}' level {level} ignored (LoRA merge not implemented)")
         g = float(req.guidance_scale)
-        neg = None
         with torch.cuda.stream(self.pipe.stream):
-            pe = self._encode([req.prompt])
-            if g > 1.0 and not self.pipe.unet.has_cond:
-                neg = self._encode([""])
-        out = self.pipe.generate(pe, [seed], width, height, int(req.num_inference_steps), g, negative_embeds=neg)
+            pe, kw = self._conditioning(req, width, height, g)
+        out = self.pipe.generate(pe, [seed], width, height, int(req.num_inference_steps), g, **kw)
         return out, seed
 
     def run_job(self, job) -> Tuple[bytes, int]:
@@ -160,3 +176,49 @@ class HipLcmWorker:
             self.close()
         except Exception:
             pass
+
+
+class HipLcmSDXLWorker(HipLcmWorker):
+    """SDXL worker (drop-in for DiffusersSDXLCudaWorker, backends/cuda_worker.py:307-614): two text encoders
+    (CLIP-L hidden_states[-2] | OpenCLIP-bigG hidden_states[-2] -> 2048; pooled bigG text_embeds), size/crop time ids,
+    classifier-free guidance when guidance_scale > 1 (negative conditioning = zeros, force_zeros_for_empty_prompt)."""
+
+    FAMILY = "sdxl"
+
+    def _synthetic_weights(self):
+        from ..config import SDXL_UNET, unet_config, vae_config
+        ucfg = unet_config(SDXL_UNET)
+        vcfg = vae_config(dict(scaling_factor=0.13025, sample_size=1024))
+        return (_weights.synthetic_state_dict(_weights.unet_param_spec(ucfg), 0), ucfg,
+                _weights.synthetic_state_dict(_weights.vae_param_spec(vcfg), 1), vcfg)
+
+    def _load_text_encoders(self, device, ckpt_root, clip_sd):
+        from ..clip import CLIP_BIGG, CLIP_L, ClipTextHip, HashTokenizer, load_clip_dir, synthetic_clip
+        from ..prompt import _BpeTokenizer
+        self._enc, self._tok = [], []
+        for sub, tsub, cfg0, seed in (("text_encoder", "tokenizer", CLIP_L, 2), ("text_encoder_2", "tokenizer_2", CLIP_BIGG, 3)):
+            d = os.path.join(ckpt_root, sub) if ckpt_root else None
+            if d and os.path.isdir(d):
+                sd, cfg = load_clip_dir(d)
+                cfg = dict(cfg0, **cfg)
+            else:
+                sd, cfg = synthetic_clip(cfg0, seed=seed), cfg0
+            self._enc.append(ClipTextHip(sd, cfg, device=device))
+            td = os.path.join(ckpt_root, tsub) if ckpt_root else None
+            self._tok.append(_BpeTokenizer(td) if td and os.path.isdir(td) else HashTokenizer(cfg["vocab_size"]))
+        if self._enc[0].D + self._enc[1].D != self.pipe.unet.ctx_dim:
+            raise RuntimeError("text encoder widths do not add up to the UNet cross_attention_dim")
+
+    def _text_bytes(self):
+        return sum(e.weight_bytes() for e in self._enc)
+
+    def _conditioning(self, req, width, height, guidance):
+        h1 = self._enc[0].forward(self._tok[0]([req.prompt]), output="penultimate")
+        h2, pooled = self._enc[1].forward(self._tok[1]([req.prompt]), output="penultimate", pooled=True)
+        pe = torch.cat([h1, h2], dim=-1)
+        tids = torch.tensor([[float(height), float(width), 0.0, 0.0, float(height), float(width)]])
+        kw = dict(added=(pooled, tids))
+        if guidance > 1.0 and not self.pipe.unet.has_cond:
+            kw["negative_embeds"] = torch.zeros_like(pe)
+            kw["negative_added"] = (torch.zeros_like(pooled), tids)
+        return pe, kw

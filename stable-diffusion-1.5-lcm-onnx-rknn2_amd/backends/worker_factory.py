@@ -10,8 +10,8 @@ def detect_worker_type() -> str:
     """cross_attention_dim -> 'sd15' | 'sdxl' (backends/worker_factory.py:55-67)."""
     root = (os.environ.get("MODEL_ROOT") or "").strip()
     name = (os.environ.get("MODEL") or "").strip()
-    if name == "synthetic":
-        return "sd15"
+    if name.startswith("synthetic"):
+        return "sdxl" if name.endswith("sdxl") else "sd15"
     if not root:
         raise RuntimeError("MODEL_ROOT environment variable is required")
     if not name:
@@ -41,7 +41,7 @@ def detect_worker_type() -> str:
 
 def create_hip_worker(worker_id: int):
     kind = detect_worker_type()
-    if kind != "sd15":
-        raise RuntimeError("SDXL checkpoints are not supported by the HIP backend yet")
-    from .hip_worker import HipLcmWorker
-    return HipLcmWorker(worker_id=worker_id)
+    from .hip_worker import HipLcmSDXLWorker, HipLcmWorker
+    if kind == "sdxl":
+        return HipLcmSDXLWorker(worker_id=worker_id)                 # backends/worker_factory.py:93
+    return HipLcmWorker(worker_id=worker_id)                         # backends/worker_factory.py:97

@@ -89,8 +89,6 @@ def test_factory_detects_family_from_checkpoint(tmp_path, monkeypatch):
     j["cross_attention_dim"] = 2048
     json.dump(j, open(cfgp, "w"))
     assert worker_factory.detect_worker_type() == "sdxl"
-    with pytest.raises(RuntimeError, match="SDXL"):
-        worker_factory.create_hip_worker(worker_id=0)
     j["cross_attention_dim"] = 999
     json.dump(j, open(cfgp, "w"))
     with pytest.raises(RuntimeError, match="Unknown cross_attention_dim"):

@@ -85,3 +85,31 @@ def test_random_seed(worker):
     p1, s1 = worker.run_job(job)
     p2, s2 = worker.run_job(job)
     assert 0 <= s1 < 100_000_000 and 0 <= s2 < 100_000_000 and s1 != s2 and p1 != p2
+
+
+def test_sdxl_worker_contract():
+    """DiffusersSDXLCudaWorker's behavioural contract (tests/test_sdxl_worker.py in the reference) on the SDXL-family HIP
+    worker with synthetic full-size SDXL weights: (bytes,int), PNG, seed echo, determinism, 512-byte latents, CFG path."""
+    os.environ["MODEL"] = "synthetic-sdxl"
+    from sdlcm_amd.backends.worker_factory import create_hip_worker
+    from sdlcm_amd.backends.hip_worker import HipLcmSDXLWorker
+    w = create_hip_worker(worker_id=1)
+    try:
+        assert isinstance(w, HipLcmSDXLWorker) and w.worker_id == 1
+        job = MockJob(MockGenerateRequest(prompt="a beautiful mountain landscape at sunset", size="256x256", seed=12345,
+                                          num_inference_steps=2))
+        png, seed = w.run_job(job)
+        assert seed == 12345 and png[:8] == b"\x89PNG\r\n\x1a\n" and len(png) > 1000
+        png2, _ = w.run_job(job)
+        assert png2 == png
+        p3, s3, lat = w.run_job_with_latents(job)
+        assert p3 == png and len(lat) == 512
+        cfg_job = MockJob(MockGenerateRequest(prompt="a serene lake", size="256x256", seed=7, num_inference_steps=2, guidance_scale=5.0))
+        p4, _ = w.run_job(cfg_job)
+        p5, _ = w.run_job(cfg_job)
+        assert p4 == p5 and p4 != png
+        with pytest.raises(RuntimeError, match="Invalid size"):
+            w.run_job(MockJob(MockGenerateRequest(prompt="x", size="bad", seed=1)))
+    finally:
+        w.close()
+        os.environ["MODEL"] = "synthetic"
