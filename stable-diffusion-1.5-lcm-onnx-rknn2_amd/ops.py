@@ -294,13 +294,13 @@ def set_kernel_variant(v):
     _lib.check(_lib.load().lcm_set_kernel_variant(int(v)), "lcm_set_kernel_variant")
 
 
-def profile_begin(max_launches=8192):
+def profile_begin(max_launches=1 << 17):
     _lib.check(_lib.load().lcm_profile_begin(int(max_launches)), "lcm_profile_begin")
 
 
 def profile_end():
     """-> list of (kernel instantiation, milliseconds) in launch order."""
-    buf = C.create_string_buffer(1 << 20)
+    buf = C.create_string_buffer(1 << 24)
     n = _lib.load().lcm_profile_end(buf, len(buf))
     if n < 0:
         _lib.check(n, "lcm_profile_end")
