@@ -67,6 +67,12 @@ class _Plan:
     """Buffers + captured graph for one (B, h, w, steps, cfg) key."""
 
     def __init__(self, pipe, B, h, w, steps, do_cfg):
+        # Every zero-fill below must be ordered before the first use on the pipeline's (non-blocking) stream: allocate
+        # under that stream, or a fill still queued on the null stream can land AFTER the request's uploads.
+        with torch.cuda.stream(pipe.stream):
+            self._init(pipe, B, h, w, steps, do_cfg)
+
+    def _init(self, pipe, B, h, w, steps, do_cfg):
         dev = pipe.device
         self.B, self.h, self.w, self.steps, self.do_cfg = B, h, w, steps, do_cfg
         UB = 2 * B if do_cfg else B

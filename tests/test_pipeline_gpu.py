@@ -104,6 +104,7 @@ def test_non_square_768x512_parity(state):
     ref = ora(pe.float(), 768, 512, 2, 1.0, 11)
     out = hip.generate(pe, [11], 768, 512, 2, 1.0, want_float=True)
     assert out["rgb"].shape == (1, 512, 768, 3)
+    _report("768x512 latents", out["latents"], ref["latents"])
     a = np.clip(out["image"].transpose(0, 3, 1, 2) / 2 + 0.5, 0, 1)
     b = np.clip(ref["image"] / 2 + 0.5, 0, 1)
     e = _report("768x512 2-step image[0,1]", a, b)
