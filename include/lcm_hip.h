@@ -197,6 +197,11 @@ int lcm_profile_end(char* out, int64_t cap);
 /* profiling aid: hold the stream busy for `usec` (<= 2 s) so queued launches run back to back */
 int lcm_debug_spin(int usec, void* stream);
 
+/* ---- LoRA style merge: out = base + alpha * delta over n fp16 elements (n % 8 == 0); out may alias the live weight.
+ * Replaces pipe.set_adapters([name],[weight]) / disable_lora() of backends/cuda_worker.py:165-196 (weights are
+ * re-merged in place, so captured graphs stay valid). */
+int lcm_axpy_f16(const void* base, const void* delta, float alpha, void* out, int64_t n, void* stream);
+
 /* ---- hipGraph capture of the 4-step sampler loop + VAE ---- */
 int lcm_graph_begin(void* stream);
 int lcm_graph_end(void* stream, void** graph_exec_out);

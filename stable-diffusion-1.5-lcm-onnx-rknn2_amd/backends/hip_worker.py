@@ -116,9 +116,49 @@ class HipLcmWorker:
             self._load_text_encoders(device, ckpt_root, clip_sd)
         self.device = device
         self.dtype = torch.float16
+        self._styles, self._active_style = {}, None
+        self._load_styles()
         print(f"[hip] worker {worker_id} ({self.FAMILY}) loaded: {os.path.basename(ckpt)} ({format_name}) on {device} dtype=fp16 "
               f"unet={self.pipe.unet.weight_bytes() / 1e9:.2f}GB vae={self.pipe.vae.weight_bytes() / 1e9:.2f}GB "
               f"text={self._text_bytes() / 1e9:.2f}GB")
+
+    # ---- style LoRAs (backends/cuda_worker.py:123-196) -----------------------------------------
+    def _load_styles(self):
+        from ..lora import LoraStyle
+        from .styles import STYLE_REGISTRY
+        cad = int(self.pipe.unet.ctx_dim)
+        for sid, sd in STYLE_REGISTRY.items():
+            if sd.required_cross_attention_dim is not None and int(sd.required_cross_attention_dim) != cad:
+                print(f"[hip] skip style '{sid}': incompatible cross_attention_dim (model={cad} style={sd.required_cross_attention_dim})")
+                continue
+            path = sd.path()
+            if not os.path.exists(path):
+                print(f"[hip] style '{sid}': LoRA file {path} not found; style disabled")
+                continue
+            try:
+                from safetensors.torch import load_file
+                with torch.cuda.stream(self.pipe.stream):
+                    st = LoraStyle(self.pipe.unet, load_file(path))
+                self._styles[sid] = st
+                print(f"[hip] loaded style LoRA: {sid} -> {path} ({len(st.modules)} modules, {len(st.skipped)} tensors skipped, "
+                      f"{st.nbytes() / 1e6:.0f} MB)")
+            except Exception as e:
+                print(f"[hip] FAILED to load style LoRA {sid}: {e!r}")
+
+    def _apply_style(self, style_id, level):
+        """Exclusive style selection; level 0 / unknown style = off.  Re-merges only when the selection changes."""
+        from .styles import STYLE_REGISTRY
+        want = None
+        if style_id and int(level) > 0 and style_id in self._styles:
+            want = (style_id, STYLE_REGISTRY[style_id].weight_for(level))
+        if want == self._active_style:
+            return
+        with torch.cuda.stream(self.pipe.stream):
+            if self._active_style is not None and (want is None or want[0] != self._active_style[0]):
+                self._styles[self._active_style[0]].apply(0.0)
+            if want is not None:
+                self._styles[want[0]].apply(want[1])
+        self._active_style = want
 
     # ---- family hooks -----------------------------------------------------------------------
     def _synthetic_weights(self):
@@ -145,10 +185,9 @@ class HipLcmWorker:
         width, height = parse_size(req.size)
         seed = int(req.seed) if getattr(req, "seed", None) is not None else int(torch.randint(0, 100_000_000, (1,)).item())
         sl = getattr(req, "style_lora", None)
+        style_id = getattr(sl, "style", None) if sl else None
         level = int(getattr(sl, "level", 0) or 0) if sl else 0
-        if level > 0 and getattr(sl, "style", None):
-            # LoRA style adapters are a later row; requests run unstyled.
-            print(f"[hip] style_lora '{sl.style}' level {level} ignored (LoRA merge not implemented)")
+        self._apply_style(style_id, level)          # lazy: no re-merge while consecutive jobs use the same style
         g = float(req.guidance_scale)
         with torch.cuda.stream(self.pipe.stream):
             pe, kw = self._conditioning(req, width, height, g)

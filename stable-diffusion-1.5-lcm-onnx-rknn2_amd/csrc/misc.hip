@@ -370,3 +370,30 @@ extern "C" int lcm_embed_tokens_f16(const void* ids, const void* tok_emb, const 
     LCM_CHECK_LAUNCH("embed_tokens");
     return LCM_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// out = base + alpha * delta (fp16 in/out, fp32 math): LoRA style merge W' = W + weight * (B A)
+// (pipe.set_adapters / disable_lora of the reference, backends/cuda_worker.py:165-196), written in place into the
+// live weight tensor so captured graphs keep their pointers.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void axpy_f16_kernel(const half_t* __restrict__ base, const half_t* __restrict__ delta,
+                                                       float alpha, half_t* __restrict__ out, long long n8) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+        h8 b = *reinterpret_cast<const h8*>(base + i * 8);
+        h8 d = *reinterpret_cast<const h8*>(delta + i * 8);
+        h8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (half_t)((float)b[j] + alpha * (float)d[j]);
+        *reinterpret_cast<h8*>(out + i * 8) = o;
+    }
+}
+
+extern "C" int lcm_axpy_f16(const void* base, const void* delta, float alpha, void* out, int64_t n, void* stream) {
+    LCM_REQUIRE(base && delta && out && n > 0 && n % 8 == 0, "axpy: bad args (n must be a multiple of 8)");
+    const long long n8 = n / 8;
+    const long long wg = (n8 + 255) / 256;
+    hipLaunchKernelGGL(axpy_f16_kernel, dim3((unsigned)(wg < 4096 ? wg : 4096)), dim3(256), 0, (hipStream_t)stream,
+                       (const half_t*)base, (const half_t*)delta, alpha, (half_t*)out, n8);
+    LCM_CHECK_LAUNCH("axpy");
+    return LCM_OK;
+}

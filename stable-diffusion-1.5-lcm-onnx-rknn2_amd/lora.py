@@ -1,0 +1,122 @@
+"""LoRA style adapters for the HIP UNet.
+
+The reference toggles adapters around every job (``pipe.set_adapters([name],[weight])`` / ``disable_lora()``,
+backends/cuda_worker.py:165-196).  Here a style is a set of per-weight deltas (B A) * alpha / rank, pre-packed into the
+kernel layouts (fused q|k|v rows, the stacked cross-attention K/V matrix, GEGLU interleave); switching a style re-merges
+W' = W + weight * delta IN PLACE with the ``lcm_axpy_f16`` kernel, so captured hipGraphs keep their weight pointers.
+
+Supported targets: every Linear / 1x1-conv of the transformer blocks (proj_in/out, attn1/attn2 to_q/k/v/out, ff);
+key styles: kohya (``lora_unet_<path>.lora_down.weight`` / ``.lora_up.weight`` / ``.alpha``) and peft / diffusers
+(``unet.<path>.lora_A.weight`` / ``.lora_B.weight``).  Conv (LoCon) and text-encoder LoRA entries are reported and skipped.
+"""
+from __future__ import annotations
+
+import re
+
+import torch
+
+from . import ops
+from .packing import pack_geglu
+from .weights import unet_param_spec
+
+
+def _target_modules(cfg):
+    out = {}
+    for name, shape, kind in unet_param_spec(cfg):
+        if not name.endswith(".weight") or ".attentions." not in name or kind not in ("w", "w_res"):
+            continue
+        out[name[:-7]] = tuple(shape)
+    return out
+
+
+def parse_lora(raw: dict, cfg) -> tuple[dict, list]:
+    """raw safetensors dict -> ({module_path: (down[r,in], up[out,r], alpha)}, skipped keys)."""
+    mods = _target_modules(cfg)
+    by_kohya = {"lora_unet_" + m.replace(".", "_"): m for m in mods}
+    found, skipped = {}, []
+    alphas = {k[:-6]: float(v) for k, v in raw.items() if k.endswith(".alpha")}
+    for k, v in raw.items():
+        if k.endswith(".alpha"):
+            continue
+        m = re.match(r"^(.*)\.(lora_down|lora_up|lora_A|lora_B)\.weight$", k)
+        if not m:
+            skipped.append(k)
+            continue
+        stem, part = m.group(1), m.group(2)
+        mod = by_kohya.get(stem)
+        if mod is None:
+            s2 = stem[5:] if stem.startswith("unet.") else stem
+            s2 = s2.replace(".processor", "")
+            mod = s2 if s2 in mods else None
+        if mod is None:
+            skipped.append(k)
+            continue
+        e = found.setdefault(mod, {"alpha": alphas.get(stem)})
+        e["down" if part in ("lora_down", "lora_A") else "up"] = v.float().reshape(v.shape[0], -1)
+    out = {}
+    for mod, e in found.items():
+        if "down" in e and "up" in e:
+            r = e["down"].shape[0]
+            out[mod] = (e["down"], e["up"], e["alpha"] if e["alpha"] is not None else float(r))
+    return out, skipped
+
+
+class LoraStyle:
+    """Deltas of one LoRA, packed for a given UNetHip; ``apply(weight)`` re-merges them in place."""
+
+    def __init__(self, unet, raw: dict):
+        parsed, self.skipped = parse_lora(raw, unet.cfg)
+        self.unet = unet
+        self.modules = sorted(parsed)
+        deltas = {}
+
+        def acc(name, rows, d):
+            w = unet.w[name]
+            t = deltas.get(name)
+            if t is None:
+                t = torch.zeros(w.shape, dtype=torch.float32)
+                deltas[name] = t
+            t[rows[0]:rows[1]] += d
+
+        for mod, (down, up, alpha) in parsed.items():
+            d = (up @ down) * (alpha / down.shape[0])                        # [out, in]
+            m = re.match(r"^(.*\.attentions\.\d+)\.(.*)$", mod)
+            p, rest = m.group(1), m.group(2)
+            if rest in ("proj_in", "proj_out"):
+                acc(f"{p}.{rest}.w", (0, d.shape[0]), d)
+                continue
+            k, sub = re.match(r"^transformer_blocks\.(\d+)\.(.*)$", rest).groups()
+            q, C = f"{p}.{k}", d.shape[0]
+            if sub.startswith("attn1.to_") and sub[-1] in "qkv":
+                i = "qkv".index(sub[-1])
+                acc(q + ".qkv.w", (i * C, (i + 1) * C), d)
+            elif sub == "attn1.to_out.0":
+                acc(q + ".o1.w", (0, C), d)
+            elif sub == "attn2.to_q":
+                acc(q + ".q2.w", (0, C), d)
+            elif sub in ("attn2.to_k", "attn2.to_v"):
+                off, Ck = unet.kv_off[q]
+                o = off + (Ck if sub.endswith("v") else 0)
+                acc("kv_all.w", (o, o + Ck), d)
+            elif sub == "attn2.to_out.0":
+                acc(q + ".o2.w", (0, C), d)
+            elif sub == "ff.net.0.proj":
+                dp, _ = pack_geglu(d, None)
+                acc(q + ".ff1.w", (0, dp.shape[0]), dp)
+            elif sub == "ff.net.2":
+                acc(q + ".ff2.w", (0, C), d)
+        dev = unet.device
+        self.delta = {n: t.to(torch.float16).to(dev).contiguous() for n, t in deltas.items()}
+        self.base = {n: unet.w[n].clone() for n in self.delta}
+        self.current = 0.0
+
+    def nbytes(self):
+        return 2 * sum(t.numel() * 2 for t in self.delta.values())
+
+    def apply(self, weight: float):
+        weight = float(weight)
+        if weight == self.current:
+            return
+        for n, d in self.delta.items():
+            ops.axpy(self.base[n], d, weight, self.unet.w[n])
+        self.current = weight

@@ -311,6 +311,12 @@ def profile_end():
     return out
 
 
+def axpy(base, delta, alpha, out):
+    """out = base + alpha * delta (fp16, fp32 math); out may be the live weight tensor."""
+    _lib.check(_lib.load().lcm_axpy_f16(_p(base), _p(delta), float(alpha), _p(out), base.numel(), _stream()), "lcm_axpy_f16")
+    return out
+
+
 def debug_spin(usec):
     _lib.check(_lib.load().lcm_debug_spin(int(usec), _stream()), "lcm_debug_spin")
 

@@ -152,3 +152,42 @@ def test_hash_tokenizer_layout():
     assert a[0, 0] == 49406 and a[0, 3] == 49407 and (a[0, 3:] == 49407).all()          # BOS w1 w2 EOS pad...
     assert c[0, 0] == 49406 and c[0, 76] == 49407 and c.shape == (1, 77)                 # truncated to 77
     assert weights.count_params(clip_param_spec()) == 123_060_480                          # CLIP-L text model
+
+
+def test_lora_key_parsing_kohya_and_peft():
+    from sdlcm_amd.config import unet_config
+    from sdlcm_amd.lora import parse_lora
+    cfg = unet_config(dict(block_out_channels=(64, 128, 128, 128), attention_head_dim=8, cross_attention_dim=96))
+    r = 4
+    raw = {
+        # kohya naming: dots flattened to underscores, separate alpha
+        "lora_unet_down_blocks_0_attentions_1_transformer_blocks_0_attn1_to_q.lora_down.weight": torch.randn(r, 64),
+        "lora_unet_down_blocks_0_attentions_1_transformer_blocks_0_attn1_to_q.lora_up.weight": torch.randn(64, r),
+        "lora_unet_down_blocks_0_attentions_1_transformer_blocks_0_attn1_to_q.alpha": torch.tensor(2.0),
+        "lora_unet_mid_block_attentions_0_proj_in.lora_down.weight": torch.randn(r, 128, 1, 1),
+        "lora_unet_mid_block_attentions_0_proj_in.lora_up.weight": torch.randn(128, r, 1, 1),
+        # peft / diffusers naming
+        "unet.up_blocks.1.attentions.2.transformer_blocks.0.attn2.to_k.lora_A.weight": torch.randn(r, 96),
+        "unet.up_blocks.1.attentions.2.transformer_blocks.0.attn2.to_k.lora_B.weight": torch.randn(128, r),
+        # not handled: text encoder + resnet conv
+        "lora_te_text_model_encoder_layers_0_mlp_fc1.lora_down.weight": torch.randn(r, 768),
+        "lora_unet_down_blocks_0_resnets_0_conv1.lora_down.weight": torch.randn(r, 64, 3, 3),
+    }
+    parsed, skipped = parse_lora(raw, cfg)
+    assert set(parsed) == {"down_blocks.0.attentions.1.transformer_blocks.0.attn1.to_q", "mid_block.attentions.0.proj_in",
+                           "up_blocks.1.attentions.2.transformer_blocks.0.attn2.to_k"}
+    d, u, a = parsed["down_blocks.0.attentions.1.transformer_blocks.0.attn1.to_q"]
+    assert d.shape == (r, 64) and u.shape == (64, r) and a == 2.0
+    assert parsed["mid_block.attentions.0.proj_in"][0].shape == (r, 128) and parsed["mid_block.attentions.0.proj_in"][2] == float(r)
+    assert len(skipped) == 2
+
+
+def test_style_registry_mirror():
+    from sdlcm_amd.backends.styles import STYLE_REGISTRY, StyleDef
+    sd = STYLE_REGISTRY["papercut"]
+    assert sd.adapter_name == "style_papercut" and sd.weight_for(1) == 0.80 and sd.weight_for(99) == 1.15 and sd.weight_for(0) == 0.80
+    os.environ["LCM_STYLE_PAPERCUT_PATH"] = "/tmp/x.safetensors"
+    try:
+        assert sd.path() == "/tmp/x.safetensors"
+    finally:
+        del os.environ["LCM_STYLE_PAPERCUT_PATH"]

@@ -261,3 +261,56 @@ def test_sdxl_style_pipeline_parity(guidance):
     d = np.abs(g1["rgb"].astype(int) - out["rgb"].astype(int))
     assert d.max() <= 2            # graph (autotuned plans) vs the earlier eager pass: summation order only
     hip.drop_plans()
+
+
+def test_lora_style_merge_parity_and_restore(state):
+    """A synthetic LoRA over every supported target kind (fused q|k|v rows, stacked cross-attention K/V, GEGLU
+    interleave, proj_in/out, out-projections, ff.net.2): the in-place merge W + weight * (BA) alpha/r must match the
+    oracle run on explicitly merged weights; weight 0 must restore the base output bit for bit."""
+    from sdlcm_amd import weights
+    from sdlcm_amd.lora import LoraStyle
+    from oracle.pipeline import LCMPipelineOracle
+    hip, ora = state["hip"], state["ora"]
+    usd = weights.synthetic_unet()
+    g = torch.Generator().manual_seed(31)
+    targets = ["down_blocks.0.attentions.0.proj_in", "down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_q",
+               "down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_v", "down_blocks.1.attentions.1.transformer_blocks.0.attn1.to_out.0",
+               "down_blocks.1.attentions.1.transformer_blocks.0.attn2.to_q", "mid_block.attentions.0.transformer_blocks.0.attn2.to_k",
+               "mid_block.attentions.0.transformer_blocks.0.attn2.to_v", "up_blocks.1.attentions.0.transformer_blocks.0.attn2.to_out.0",
+               "up_blocks.2.attentions.1.transformer_blocks.0.ff.net.0.proj", "up_blocks.3.attentions.2.transformer_blocks.0.ff.net.2",
+               "up_blocks.3.attentions.2.proj_out"]
+    raw, r, alpha, wt = {}, 8, 4.0, 0.9
+    merged = dict(usd)
+    for i, m in enumerate(targets):
+        W = usd[m + ".weight"]
+        out_f, in_f = W.shape[0], W.reshape(W.shape[0], -1).shape[1]
+        down = torch.randn(r, in_f, generator=g) * (in_f ** -0.5)
+        up = torch.randn(out_f, r, generator=g) * 0.5
+        key = "lora_unet_" + m.replace(".", "_") if i % 2 == 0 else "unet." + m
+        if i % 2 == 0:
+            raw[key + ".lora_down.weight"], raw[key + ".lora_up.weight"], raw[key + ".alpha"] = down, up, torch.tensor(alpha)
+            scale = alpha / r
+        else:
+            raw[key + ".lora_A.weight"], raw[key + ".lora_B.weight"] = down, up
+            scale = 1.0
+        delta = ((up @ down) * scale).to(torch.float16)
+        merged[m + ".weight"] = (W.float().reshape(out_f, in_f) + wt * delta.float()).to(torch.float16).reshape(W.shape)
+    pe = _embeds(1, seed=12)
+    base = hip.generate(pe, [4], 128, 128, 2, 1.0, want_float=True)
+    with torch.cuda.stream(hip.stream):
+        style = LoraStyle(hip.unet, raw)
+        assert len(style.modules) == len(targets) and not style.skipped
+        style.apply(wt)
+    try:
+        out = hip.generate(pe, [4], 128, 128, 2, 1.0, want_float=True)
+        ref = LCMPipelineOracle(merged, weights.synthetic_vae())(pe.float(), 128, 128, 2, 1.0, 4)
+        a = np.clip(out["image"].transpose(0, 3, 1, 2) / 2 + 0.5, 0, 1)
+        b = np.clip(ref["image"] / 2 + 0.5, 0, 1)
+        e = _report("lora-merged image[0,1]", a, b)
+        assert e.max() < 1e-2
+        assert np.abs(out["image"] - base["image"]).max() > 1e-3          # the style does change the picture
+    finally:
+        with torch.cuda.stream(hip.stream):
+            style.apply(0.0)
+    again = hip.generate(pe, [4], 128, 128, 2, 1.0, want_float=True)
+    assert np.array_equal(again["rgb"], base["rgb"]) and np.array_equal(again["latents"], base["latents"])
