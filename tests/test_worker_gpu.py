@@ -113,3 +113,40 @@ def test_sdxl_worker_contract():
     finally:
         w.close()
         os.environ["MODEL"] = "synthetic"
+
+
+def test_style_lora_requests(tmp_path):
+    """style_lora on the request (server/lcm_sr_server.py:106-125): the style's LoRA is merged for that job, level picks
+    the ladder weight, and an unstyled job afterwards reproduces the unstyled bytes (no state bleed, cuda_worker.py:232)."""
+    import torch
+    from safetensors.torch import save_file
+    from sdlcm_amd.backends import styles
+    from sdlcm_amd.backends.worker_factory import create_hip_worker
+    g = torch.Generator().manual_seed(1)
+    raw = {}
+    for m, (o, i) in {"down_blocks.0.attentions.0.transformer_blocks.0.attn1.to_q": (320, 320),
+                      "up_blocks.3.attentions.2.transformer_blocks.0.attn2.to_v": (320, 768),
+                      "mid_block.attentions.0.transformer_blocks.0.ff.net.0.proj": (10240, 1280)}.items():
+        k = "lora_unet_" + m.replace(".", "_")
+        raw[k + ".lora_down.weight"] = torch.randn(4, i, generator=g) * i ** -0.5
+        raw[k + ".lora_up.weight"] = torch.randn(o, 4, generator=g)
+        raw[k + ".alpha"] = torch.tensor(4.0)
+    path = str(tmp_path / "teststyle.safetensors")
+    save_file(raw, path)
+    styles.register_style(styles.StyleDef(id="teststyle", title="t", lora_path=path, adapter_name="style_test",
+                                         levels=[0.5, 1.0], required_cross_attention_dim=768))
+    os.environ["MODEL"] = "synthetic"
+    w = create_hip_worker(worker_id=2)
+    try:
+        assert "teststyle" in w._styles and "papercut" not in w._styles           # papercut file absent -> disabled, no crash
+        req = dict(prompt="a paper boat", size="128x128", seed=5, num_inference_steps=2)
+        plain, _ = w.run_job(MockJob(MockGenerateRequest(**req)))
+        s1, _ = w.run_job(MockJob(MockGenerateRequest(**req, style_lora=MockStyleLora("teststyle", 1))))
+        s2, _ = w.run_job(MockJob(MockGenerateRequest(**req, style_lora=MockStyleLora("teststyle", 2))))
+        s2b, _ = w.run_job(MockJob(MockGenerateRequest(**req, style_lora=MockStyleLora("teststyle", 7))))   # clamped to the last level
+        unknown, _ = w.run_job(MockJob(MockGenerateRequest(**req, style_lora=MockStyleLora("nope", 2))))
+        again, _ = w.run_job(MockJob(MockGenerateRequest(**req)))
+        assert s1 != plain and s2 != s1 and s2b == s2 and unknown == plain and again == plain
+    finally:
+        w.close()
+        styles.STYLE_REGISTRY.pop("teststyle", None)
