@@ -197,6 +197,14 @@ int lcm_profile_end(char* out, int64_t cap);
 /* profiling aid: hold the stream busy for `usec` (<= 2 s) so queued launches run back to back */
 int lcm_debug_spin(int usec, void* stream);
 
+/* ---- AutoencoderKL.tiled_decode glue (vae.enable_tiling(), backends/cuda_worker.py:91): decoded tiles are fp32
+ * pixel-major [B,h,w,3].  blend: vertical=1 -> b[y] = a[ah-extent+y]*(1-y/extent) + b[y]*(y/extent) for y < extent (aw == bw);
+ * vertical=0 -> the same along x (ah == bh).  place_tile: crop [0:ch, 0:cw] of a tile into the RGB8 image at (oy, ox) with
+ * the (x/2+0.5).clamp * 255 -> rint conversion (optional fp32 copy). */
+int lcm_vae_blend_f32(const void* a, int ah, int aw, void* b, int bh, int bw, int B, int extent, int vertical, void* stream);
+int lcm_vae_place_tile(const void* tile, int th, int tw, void* out_u8, void* out_f32, int H, int W, int B,
+                       int oy, int ox, int ch, int cw, void* stream);
+
 /* ---- LoRA style merge: out = base + alpha * delta over n fp16 elements (n % 8 == 0); out may alias the live weight.
  * Replaces pipe.set_adapters([name],[weight]) / disable_lora() of backends/cuda_worker.py:165-196 (weights are
  * re-merged in place, so captured graphs stay valid). */

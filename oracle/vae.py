@@ -52,7 +52,55 @@ class VAEDecoderOracle:
         return out
 
     @torch.inference_mode()
-    def decode(self, latents):
+    def decode(self, latents, use_tiling=True):
+        """AutoencoderKL.decode with ``enable_tiling()`` as the reference sets it (backends/cuda_worker.py:91): the plain
+        path unless a latent side exceeds tile_latent_min_size = sample_size / 8, then overlapping tiles."""
+        tmin = int(self.cfg.get("sample_size", 512)) // 8
+        if use_tiling and (latents.shape[-1] > tmin or latents.shape[-2] > tmin):
+            return self.tiled_decode(latents)
+        return self.decode_plain(latents)
+
+    @staticmethod
+    def _blend_v(a, b, extent):
+        extent = min(a.shape[2], b.shape[2], extent)
+        for y in range(extent):
+            b[:, :, y, :] = a[:, :, -extent + y, :] * (1 - y / extent) + b[:, :, y, :] * (y / extent)
+        return b
+
+    @staticmethod
+    def _blend_h(a, b, extent):
+        extent = min(a.shape[3], b.shape[3], extent)
+        for x in range(extent):
+            b[:, :, :, x] = a[:, :, :, -extent + x] * (1 - x / extent) + b[:, :, :, x] * (x / extent)
+        return b
+
+    @torch.inference_mode()
+    def tiled_decode(self, latents, overlap=0.25):
+        """diffusers AutoencoderKL.tiled_decode restated: tiles of tile_latent_min_size every 75 % of it, decoded
+        independently, linearly blended over 25 % of the tile, cropped and concatenated."""
+        sample = int(self.cfg.get("sample_size", 512))
+        tl = sample // 8
+        stride = int(tl * (1 - overlap))
+        extent = int(sample * overlap)
+        limit = sample - extent
+        H, W = latents.shape[2:]
+        rows = []
+        for i in range(0, H, stride):
+            rows.append([self.decode_plain(latents[:, :, i:i + tl, j:j + tl]).clone() for j in range(0, W, stride)])
+        out_rows = []
+        for i, row in enumerate(rows):
+            res = []
+            for j, tile in enumerate(row):
+                if i > 0:
+                    tile = self._blend_v(rows[i - 1][j], tile, extent)
+                if j > 0:
+                    tile = self._blend_h(row[j - 1], tile, extent)
+                res.append(tile[:, :, :limit, :limit])
+            out_rows.append(torch.cat(res, dim=3))
+        return torch.cat(out_rows, dim=2)
+
+    @torch.inference_mode()
+    def decode_plain(self, latents):
         """latents: UNet-space [B,4,h,w] -> image [B,3,8h,8w] in ~[-1,1] (plain, untiled path)."""
         cfg = self.cfg
         z = latents.float() / cfg["scaling_factor"]

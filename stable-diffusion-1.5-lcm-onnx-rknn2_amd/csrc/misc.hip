@@ -397,3 +397,59 @@ extern "C" int lcm_axpy_f16(const void* base, const void* delta, float alpha, vo
     LCM_CHECK_LAUNCH("axpy");
     return LCM_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// AutoencoderKL.tiled_decode glue (vae.enable_tiling(), backends/cuda_worker.py:91): linear blends of
+// overlapping decoded tiles (float pixel-major [B,h,w,3]) and the crop + place + RGB8 conversion of the result.
+// ---------------------------------------------------------------------------------------------
+__global__ void vae_blend_kernel(const float* __restrict__ a, int ah, int aw, float* __restrict__ b, int bh, int bw,
+                                 int B, int extent, int vertical) {
+    // vertical: b[y][x] = a[ah-extent+y][x] * (1 - y/extent) + b[y][x] * (y/extent), y < extent, x < bw (== aw)
+    // horizontal: b[y][x] = a[y][aw-extent+x] * (1 - x/extent) + b[y][x] * (x/extent), x < extent, y < bh (== ah)
+    const int n = vertical ? extent * bw : bh * extent;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * n * 3) return;
+    const int c = i % 3, p = (i / 3) % n, bi = i / (3 * n);
+    int y, x, ya, xa;
+    float t;
+    if (vertical) { y = p / bw; x = p - y * bw; ya = ah - extent + y; xa = x; t = (float)y / (float)extent; }
+    else { y = p / extent; x = p - y * extent; ya = y; xa = aw - extent + x; t = (float)x / (float)extent; }
+    const float av = a[(((long long)bi * ah + ya) * aw + xa) * 3 + c];
+    float* bp = b + (((long long)bi * bh + y) * bw + x) * 3 + c;
+    *bp = av * (1.0f - t) + *bp * t;
+}
+
+extern "C" int lcm_vae_blend_f32(const void* a, int ah, int aw, void* b, int bh, int bw, int B, int extent, int vertical,
+                                 void* stream) {
+    LCM_REQUIRE(a && b && B > 0 && extent > 0, "vae_blend: bad args");
+    LCM_REQUIRE(vertical ? (aw == bw && extent <= ah && extent <= bh) : (ah == bh && extent <= aw && extent <= bw),
+                "vae_blend: tile shapes %dx%d / %dx%d do not match extent %d", ah, aw, bh, bw, extent);
+    const int n = B * (vertical ? extent * bw : bh * extent) * 3;
+    hipLaunchKernelGGL(vae_blend_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)a, ah, aw,
+                       (float*)b, bh, bw, B, extent, vertical);
+    LCM_CHECK_LAUNCH("vae_blend");
+    return LCM_OK;
+}
+
+__global__ void vae_place_tile_kernel(const float* __restrict__ tile, int th, int tw, unsigned char* __restrict__ out,
+                                      float* __restrict__ out_f32, int H, int W, int B, int oy, int ox, int ch, int cw) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * ch * cw * 3) return;
+    const int c = i % 3, x = (i / 3) % cw, y = (i / (3 * cw)) % ch, bi = i / (3 * cw * ch);
+    const float v = tile[(((long long)bi * th + y) * tw + x) * 3 + c];
+    const long long o = (((long long)bi * H + oy + y) * W + ox + x) * 3 + c;
+    if (out_f32) out_f32[o] = v;
+    const float u = fminf(fmaxf(v * 0.5f + 0.5f, 0.f), 1.f);
+    out[o] = (unsigned char)rintf(u * 255.f);
+}
+
+extern "C" int lcm_vae_place_tile(const void* tile, int th, int tw, void* out_u8, void* out_f32, int H, int W, int B,
+                                  int oy, int ox, int ch, int cw, void* stream) {
+    LCM_REQUIRE(tile && out_u8 && B > 0, "vae_place_tile: bad args");
+    LCM_REQUIRE(ch <= th && cw <= tw && oy >= 0 && ox >= 0 && oy + ch <= H && ox + cw <= W, "vae_place_tile: crop outside bounds");
+    const int n = B * ch * cw * 3;
+    hipLaunchKernelGGL(vae_place_tile_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)tile, th,
+                       tw, (unsigned char*)out_u8, (float*)out_f32, H, W, B, oy, ox, ch, cw);
+    LCM_CHECK_LAUNCH("vae_place_tile");
+    return LCM_OK;
+}

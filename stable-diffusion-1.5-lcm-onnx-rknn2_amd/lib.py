@@ -54,6 +54,8 @@ _SIGS = {
     "lcm_gemm_tile_config": [_i, _i, _i],
     "lcm_debug_spin": [_i, _vp],
     "lcm_axpy_f16": [_vp, _vp, _f, _vp, _i64, _vp],
+    "lcm_vae_blend_f32": [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp],
+    "lcm_vae_place_tile": [_vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "lcm_profile_begin": [_i],
     "lcm_profile_end": [C.c_char_p, _i64],
     "lcm_set_workspace": [_vp, _i64],

@@ -410,7 +410,49 @@ class VAEDecoderHip(_Net):
         ops.gemm(o, w["attn.o.w"], out, bias=w["attn.o.b"], res=x, stats=out_st, stats_hw=S)
         return out, out_st
 
-    def decode(self, lat, B, h, w_, rgb_out, img_f32=None, taps=None):
+    def decode(self, lat, B, h, w_, rgb_out, img_f32=None, taps=None, use_tiling=True):
+        """AutoencoderKL.decode with vae.enable_tiling() as the reference sets it (backends/cuda_worker.py:91): plain
+        unless a latent side exceeds sample_size / 8, then diffusers' overlapping-tile decode."""
+        tmin = int(self.cfg.get("sample_size", 512)) // 8
+        if use_tiling and (h > tmin or w_ > tmin):
+            return self.decode_tiled(lat, B, h, w_, rgb_out, img_f32)
+        return self.decode_plain(lat, B, h, w_, rgb_out, img_f32, taps)
+
+    def decode_tiled(self, lat, B, h, w_, rgb_out, img_f32=None, overlap=0.25):
+        sample = int(self.cfg.get("sample_size", 512))
+        tl = sample // 8
+        stride, extent = int(tl * (1 - overlap)), int(sample * overlap)
+        limit = sample - extent
+        H, W = 8 * h, 8 * w_
+        ys, xs = list(range(0, h, stride)), list(range(0, w_, stride))
+        tiles = {}
+        for i, y0 in enumerate(ys):
+            for j, x0 in enumerate(xs):
+                th, tw = min(tl, h - y0), min(tl, w_ - x0)
+                sub = self.buf.get("tile_lat", B, 4, th, tw, dtype=torch.float32)
+                sub.copy_(lat[:, :, y0:y0 + th, x0:x0 + tw])                       # strided gather of the latent tile
+                img = self.buf.get(f"tile_img_{i}_{j}", B, 8 * th, 8 * tw, 3, dtype=torch.float32)
+                scratch = self.buf.get("tile_u8", B, 8 * th, 8 * tw, 3, dtype=torch.uint8)
+                self.decode_plain(sub, B, th, tw, scratch, img_f32=img)
+                tiles[(i, j)] = (img, 8 * th, 8 * tw)
+        oy = 0
+        for i in range(len(ys)):
+            ox = 0
+            for j in range(len(xs)):
+                img, th, tw = tiles[(i, j)]
+                if i > 0:
+                    a, ah, aw = tiles[(i - 1, j)]
+                    ops.vae_blend(a, ah, aw, img, th, tw, B, min(ah, th, extent), True)
+                if j > 0:
+                    a, ah, aw = tiles[(i, j - 1)]
+                    ops.vae_blend(a, ah, aw, img, th, tw, B, min(aw, tw, extent), False)
+                ch, cw = min(limit, th), min(limit, tw)
+                ops.vae_place_tile(img, th, tw, rgb_out, img_f32, H, W, B, oy, ox, ch, cw)
+                ox += cw
+            oy += min(limit, tiles[(i, 0)][1])
+        return rgb_out
+
+    def decode_plain(self, lat, B, h, w_, rgb_out, img_f32=None, taps=None):
         """lat fp32 [B,4,h,w] (UNet space) -> rgb_out u8 [B,8h,8w,3]; optional fp32 NHWC image copy."""
         cfg, wt = self.cfg, self.w
         boc = cfg["block_out_channels"]

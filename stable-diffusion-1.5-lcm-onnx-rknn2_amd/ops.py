@@ -317,6 +317,15 @@ def axpy(base, delta, alpha, out):
     return out
 
 
+def vae_blend(a, ah, aw, b, bh, bw, B, extent, vertical):
+    _lib.check(_lib.load().lcm_vae_blend_f32(_p(a), ah, aw, _p(b), bh, bw, B, extent, 1 if vertical else 0, _stream()), "lcm_vae_blend_f32")
+
+
+def vae_place_tile(tile, th, tw, out_u8, out_f32, H, W, B, oy, ox, ch, cw):
+    _lib.check(_lib.load().lcm_vae_place_tile(_p(tile), th, tw, _p(out_u8), _p(out_f32), H, W, B, oy, ox, ch, cw, _stream()),
+               "lcm_vae_place_tile")
+
+
 def debug_spin(usec):
     _lib.check(_lib.load().lcm_debug_spin(int(usec), _stream()), "lcm_debug_spin")
 

@@ -81,6 +81,34 @@ def test_vae_decode_parity(state):
     assert np.abs(rgb.cpu().numpy().astype(int) - u8.astype(int)).max() <= 3
 
 
+@pytest.mark.parametrize("h,w", [(48, 40), (32, 72), (56, 56)])
+def test_vae_tiled_decode_parity(state, h, w):
+    """vae.enable_tiling() (backends/cuda_worker.py:91): latents larger than sample_size/8 take diffusers' overlapping
+    tile decode; a 256-px sample_size keeps the case small (2x2 ragged, 1x3, 3x3 tiles; latent sides stay multiples
+    of 8 as every request size the worker accepts gives)."""
+    hip, ora = state["hip"], state["ora"]
+    B = 2
+    lat = torch.randn(B, 4, h, w, generator=torch.Generator().manual_seed(h * 100 + w)) * 0.9
+    old_o, old_h = ora.vae.cfg.get("sample_size", 512), hip.vae.cfg.get("sample_size", 512)
+    ora.vae.cfg["sample_size"] = hip.vae.cfg["sample_size"] = 256
+    try:
+        ref = ora.vae.decode(lat).numpy()
+        plain = ora.vae.decode(lat, use_tiling=False).numpy()
+        with torch.cuda.stream(hip.stream):
+            rgb = torch.zeros(B, 8 * h, 8 * w, 3, dtype=torch.uint8, device=hip.device)
+            img = torch.zeros(B, 8 * h, 8 * w, 3, dtype=torch.float32, device=hip.device)
+            hip.vae.decode(lat.to(hip.device), B, h, w, rgb, img_f32=img)
+            hip.stream.synchronize()
+    finally:
+        ora.vae.cfg["sample_size"], hip.vae.cfg["sample_size"] = old_o, old_h
+    assert np.abs(ref - plain).max() > 1e-2          # the tiled result really is a different image
+    got = img.cpu().numpy().transpose(0, 3, 1, 2)
+    e = _report(f"tiled vae {h}x{w}", np.clip(got / 2 + 0.5, 0, 1), np.clip(ref / 2 + 0.5, 0, 1))
+    assert e.max() < 1e-2
+    from oracle import glue
+    assert np.abs(rgb.cpu().numpy().astype(int) - glue.postprocess_u8(ref).astype(int)).max() <= 3
+
+
 @pytest.mark.parametrize("size,steps,seed", [(128, 4, 42), (64, 1, 7), (192, 2, 1234)])
 def test_end_to_end_parity(state, size, steps, seed):
     hip, ora = state["hip"], state["ora"]
