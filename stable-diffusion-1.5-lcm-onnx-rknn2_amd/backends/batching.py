@@ -1,0 +1,100 @@
+"""Queue-level micro-batching inside the worker.
+
+The reference runs one ``self.pipe(...)`` per job and one worker thread per ``worker_id``
+(backends/worker_pool.py:73-120, backends/cuda_worker.py:198-252).  On an MI355X a batch-8 sampler pass costs ~3.5x a
+batch-1 pass, so jobs that are queued at the same moment and agree on (size, steps, guidance, style) are coalesced
+into ONE batched pass here -- below the ``run_job`` boundary, so the pool above is untouched: every caller still
+blocks in its own ``run_job`` and gets its own (png, seed) back, and PNG encoding stays on the callers' threads
+(zlib releases the GIL), i.e. off the GPU dispatcher.
+
+Batch sizes are restricted to ``sizes`` (default 1, 2, 4, 8) because every batch size owns a captured hipGraph and
+its buffers: 5 waiting jobs run as 4 + 1, never as a new 5-wide plan.
+"""
+from __future__ import annotations
+
+import threading
+import time
+from collections import deque
+from concurrent.futures import Future
+from typing import Callable, Hashable, List, Sequence
+
+
+class MicroBatcher:
+    """``submit(key, item) -> Future``; a single dispatcher thread calls ``run_batch(key, [items]) -> [results]``.
+
+    Ordering: the oldest waiting item always leads the next batch (no starvation); younger items with the same key
+    join it, items with other keys keep their place.  ``window_ms`` is how long the dispatcher will wait for more
+    arrivals when the queue is shorter than ``max_batch`` -- 0 (default) never delays a lone request: coalescing then
+    comes only from jobs that queued up while the previous pass was running, which is the loaded case that matters.
+    """
+
+    def __init__(self, run_batch: Callable[[Hashable, list], list], max_batch: int = 8, window_ms: float = 0.0,
+                 sizes: Sequence[int] = (1, 2, 4, 8), name: str = "lcm-microbatch"):
+        self.run_batch = run_batch
+        self.sizes = sorted(s for s in set(int(x) for x in sizes) if 1 <= s <= max(1, int(max_batch))) or [1]
+        self.max_batch = self.sizes[-1]
+        self.window = max(0.0, float(window_ms)) / 1e3
+        self._q: deque = deque()                    # (key, item, future, t_arrival)
+        self._cv = threading.Condition()
+        self._closed = False
+        self.batches: List[int] = []                # sizes of the batches run so far (telemetry / tests)
+        self._thread = threading.Thread(target=self._loop, name=name, daemon=True)
+        self._thread.start()
+
+    def submit(self, key: Hashable, item) -> Future:
+        fut: Future = Future()
+        with self._cv:
+            if self._closed:
+                raise RuntimeError("MicroBatcher is closed")
+            self._q.append((key, item, fut, time.monotonic()))
+            self._cv.notify()
+        return fut
+
+    def _take(self):
+        """Called with the lock held and a non-empty queue: pop the next batch (same key as the head)."""
+        key = self._q[0][0]
+        same = [e for e in self._q if e[0] == key]
+        n = max(s for s in self.sizes if s <= len(same))
+        batch = same[:n]
+        ids = {id(e) for e in batch}
+        self._q = deque(e for e in self._q if id(e) not in ids)
+        return key, batch
+
+    def _loop(self):
+        while True:
+            with self._cv:
+                while not self._q and not self._closed:
+                    self._cv.wait()
+                if not self._q and self._closed:
+                    return
+                if self.window > 0:
+                    head_key, deadline = self._q[0][0], self._q[0][3] + self.window
+                    while (sum(1 for e in self._q if e[0] == head_key) < self.max_batch and not self._closed):
+                        left = deadline - time.monotonic()
+                        if left <= 0:
+                            break
+                        self._cv.wait(left)
+                key, batch = self._take()
+            items = [e[1] for e in batch]
+            try:
+                results = self.run_batch(key, items)
+                if len(results) != len(items):
+                    raise RuntimeError(f"run_batch returned {len(results)} results for {len(items)} items")
+                self.batches.append(len(items))
+                for e, r in zip(batch, results):
+                    e[2].set_result(r)
+            except BaseException as exc:            # every waiter of the failed pass sees the error (reference: the
+                for e in batch:                     # exception propagates out of run_job, backends/worker_pool.py:100-113)
+                    if not e[2].done():
+                        e[2].set_exception(exc)
+
+    def close(self, timeout: float = 30.0):
+        with self._cv:
+            self._closed = True
+            self._cv.notify_all()
+        self._thread.join(timeout)
+        with self._cv:
+            for e in self._q:
+                if not e[2].done():
+                    e[2].set_exception(RuntimeError("MicroBatcher closed before the job ran"))
+            self._q.clear()

@@ -16,6 +16,7 @@ from __future__ import annotations
 import io
 import os
 import struct
+import threading
 import zlib
 from typing import Tuple
 
@@ -67,6 +68,36 @@ def encode_png(rgb) -> bytes:
             + _png_chunk(b"IDAT", comp) + _png_chunk(b"IEND", b""))
 
 
+class _Engine:
+    """State shared by every worker the pool creates for one (family, device, checkpoint): the reference builds one
+    pipeline -- and one weight copy -- per ``worker_id`` (backends/worker_pool.py:60-71); here the workers of a GPU share
+    the resident weights, the captured graphs and one micro-batching dispatcher (backends/batching.py), so N pool
+    threads blocking in ``run_job`` become batched passes.  LCM_SHARE_ENGINE=0 restores one engine per worker."""
+
+    SHARED = ("pipe", "_encode", "_enc", "_tok", "_styles", "device", "dtype")
+
+    def __init__(self):
+        self.lock = threading.RLock()
+        self.refs = 0
+        self.batcher = None
+        self.batch_sizes = (1,)
+        self.active_style = None
+        self.first = None
+
+    def release(self) -> bool:
+        with _ENGINES_LOCK:
+            self.refs -= 1
+            if self.refs > 0:
+                return False
+            for k in [k for k, v in _ENGINES.items() if v is self]:
+                del _ENGINES[k]
+            return True
+
+
+_ENGINES: dict = {}
+_ENGINES_LOCK = threading.Lock()
+
+
 class HipLcmWorker:
     """SD1.5-family worker (drop-in for DiffusersCudaWorker, backends/cuda_worker.py:20-304)."""
 
@@ -88,6 +119,21 @@ class HipLcmWorker:
         device = (os.environ.get("HIP_DEVICE") or os.environ.get("CUDA_DEVICE") or "cuda:0").strip()
         if not torch.cuda.is_available():
             raise LcmHipError("HipLcmWorker needs an MI355X; no CPU fallback exists on this path")
+        share = os.environ.get("LCM_SHARE_ENGINE", "1").lower() not in ("0", "false", "no", "off")
+        from .styles import STYLE_REGISTRY
+        ekey = (self.FAMILY, device, "synthetic" if synthetic else os.path.join(model_root, model_name),
+                tuple(sorted((sid, sd.path()) for sid, sd in STYLE_REGISTRY.items())))
+        with _ENGINES_LOCK:
+            eng = _ENGINES.get(ekey) if share else None
+            if eng is not None:
+                eng.refs += 1
+        if eng is not None:                          # a sibling worker already holds this checkpoint on this GPU
+            self._engine = eng
+            for k in _Engine.SHARED:
+                if k in eng.first.__dict__:
+                    setattr(self, k, eng.first.__dict__[k])
+            print(f"[hip] worker {worker_id} ({self.FAMILY}) attached to the resident engine on {device} ({eng.refs} workers)")
+            return
         sched = LCMSchedule()
         clip_sd = None
         if synthetic:
@@ -116,8 +162,19 @@ class HipLcmWorker:
             self._load_text_encoders(device, ckpt_root, clip_sd)
         self.device = device
         self.dtype = torch.float16
-        self._styles, self._active_style = {}, None
+        self._styles = {}
+        self._engine = eng = _Engine()
+        eng.refs, eng.first = 1, self
         self._load_styles()
+        mb = int(os.environ.get("LCM_MICROBATCH", "8") or 0)
+        if mb > 1:
+            from .batching import MicroBatcher
+            eng.batcher = MicroBatcher(lambda key, items, w=self, e=eng: w._run_batch(key, items, e), max_batch=mb,
+                                       window_ms=float(os.environ.get("LCM_MICROBATCH_WINDOW_MS", "0") or 0))
+            eng.batch_sizes = tuple(eng.batcher.sizes)
+        if share:
+            with _ENGINES_LOCK:
+                _ENGINES.setdefault(ekey, eng)
         print(f"[hip] worker {worker_id} ({self.FAMILY}) loaded: {os.path.basename(ckpt)} ({format_name}) on {device} dtype=fp16 "
               f"unet={self.pipe.unet.weight_bytes() / 1e9:.2f}GB vae={self.pipe.vae.weight_bytes() / 1e9:.2f}GB "
               f"text={self._text_bytes() / 1e9:.2f}GB")
@@ -145,20 +202,25 @@ class HipLcmWorker:
             except Exception as e:
                 print(f"[hip] FAILED to load style LoRA {sid}: {e!r}")
 
-    def _apply_style(self, style_id, level):
+    @property
+    def _active_style(self):
+        return self._engine.active_style
+
+    def _apply_style(self, style_id, level, eng=None):
         """Exclusive style selection; level 0 / unknown style = off.  Re-merges only when the selection changes."""
         from .styles import STYLE_REGISTRY
         want = None
         if style_id and int(level) > 0 and style_id in self._styles:
             want = (style_id, STYLE_REGISTRY[style_id].weight_for(level))
-        if want == self._active_style:
+        eng = eng or self._engine
+        if want == eng.active_style:
             return
         with torch.cuda.stream(self.pipe.stream):
-            if self._active_style is not None and (want is None or want[0] != self._active_style[0]):
-                self._styles[self._active_style[0]].apply(0.0)
+            if eng.active_style is not None and (want is None or want[0] != eng.active_style[0]):
+                self._styles[eng.active_style[0]].apply(0.0)
             if want is not None:
                 self._styles[want[0]].apply(want[1])
-        self._active_style = want
+        eng.active_style = want
 
     # ---- family hooks -----------------------------------------------------------------------
     def _synthetic_weights(self):
@@ -173,41 +235,92 @@ class HipLcmWorker:
     def _text_bytes(self):
         return self._encode.enc.weight_bytes()
 
-    def _conditioning(self, req, width, height, guidance):
-        """-> kwargs for LcmHipPipeline.generate (prompt_embeds first)."""
-        pe = self._encode([req.prompt])
-        neg = self._encode([""]) if (guidance > 1.0 and not self.pipe.unet.has_cond) else None
+    def _conditioning(self, reqs, width, height, guidance):
+        """-> (prompt_embeds [B,77,ctx], kwargs for LcmHipPipeline.generate) for B requests of one batch."""
+        B = len(reqs)
+        pe = self._encode([r.prompt for r in reqs])
+        neg = None
+        if guidance > 1.0 and not self.pipe.unet.has_cond:
+            neg = self._encode([""]).expand(B, -1, -1)
         return pe, dict(negative_embeds=neg)
 
     # ------------------------------------------------------------------------------------------
-    def _generate(self, job):
-        req = job.req
+    @staticmethod
+    def _job_key(req):
+        """What must agree for jobs to share one batched pass: geometry, step count, guidance and style merge."""
         width, height = parse_size(req.size)
-        seed = int(req.seed) if getattr(req, "seed", None) is not None else int(torch.randint(0, 100_000_000, (1,)).item())
         sl = getattr(req, "style_lora", None)
         style_id = getattr(sl, "style", None) if sl else None
         level = int(getattr(sl, "level", 0) or 0) if sl else 0
-        self._apply_style(style_id, level)          # lazy: no re-merge while consecutive jobs use the same style
-        g = float(req.guidance_scale)
-        with torch.cuda.stream(self.pipe.stream):
-            pe, kw = self._conditioning(req, width, height, g)
-        out = self.pipe.generate(pe, [seed], width, height, int(req.num_inference_steps), g, **kw)
-        return out, seed
+        if not style_id or level <= 0:
+            style_id, level = None, 0
+        return (width, height, int(req.num_inference_steps), float(req.guidance_scale), style_id, level)
+
+    def _run_batch(self, key, items, eng=None):
+        """One batched sampler pass for ``items`` = [(req, seed)], all of ``key``; -> per-item (rgb, pool8 row)."""
+        width, height, steps, g, style_id, level = key
+        eng = eng or self._engine
+        with eng.lock:                               # the pipeline, its plans and the merged weights are one resource
+            self._apply_style(style_id, level, eng)  # lazy: no re-merge while consecutive batches use the same style
+            reqs = [it[0] for it in items]
+            with torch.cuda.stream(self.pipe.stream):
+                pe, kw = self._conditioning(reqs, width, height, g)
+            out = self.pipe.generate(pe, [it[1] for it in items], width, height, steps, g, **kw)
+        return [(out["rgb"][i], out["pool8"][i:i + 1]) for i in range(len(items))]
+
+    def _submit(self, job):
+        req = job.req
+        key = self._job_key(req)                     # raises the reference's size error in the caller's thread
+        seed = int(req.seed) if getattr(req, "seed", None) is not None else int(torch.randint(0, 100_000_000, (1,)).item())
+        b = self._engine.batcher
+        if b is None:
+            return self._run_batch(key, [(req, seed)])[0], seed
+        return b.submit(key, (req, seed)).result(), seed
 
     def run_job(self, job) -> Tuple[bytes, int]:
-        out, seed = self._generate(job)
-        return encode_png(out["rgb"][0]), seed
+        (rgb, _), seed = self._submit(job)
+        return encode_png(rgb), seed
 
     def run_job_with_latents(self, job) -> Tuple[bytes, int, bytes]:
         # The reference re-runs the whole pipeline for the latents (cuda_worker.py:255-283); the sampler is
         # deterministic in the seed, so the same pass's final latents are identical and are pooled on device.
-        out, seed = self._generate(job)
-        return encode_png(out["rgb"][0]), seed, out["pool8"][:1].tobytes(order="C")
+        (rgb, pool8), seed = self._submit(job)
+        return encode_png(rgb), seed, pool8.tobytes(order="C")
+
+    def run_jobs(self, jobs):
+        """Batched convenience entry (not in the reference's protocol): jobs that agree on ``_job_key`` run as one pass
+        (chunked to the plan batch sizes); PNGs are encoded on a small thread pool.  -> [(png, seed)] in job order."""
+        from concurrent.futures import ThreadPoolExecutor
+        seeds, groups = [], {}
+        for i, job in enumerate(jobs):
+            req = job.req
+            seeds.append(int(req.seed) if getattr(req, "seed", None) is not None else int(torch.randint(0, 100_000_000, (1,)).item()))
+            groups.setdefault(self._job_key(req), []).append(i)
+        rgbs = [None] * len(jobs)
+        sizes = self._engine.batch_sizes
+        for key, idx in groups.items():
+            while idx:
+                n = max(s for s in sizes if s <= len(idx))
+                part, idx = idx[:n], idx[n:]
+                for i, (rgb, _) in zip(part, self._run_batch(key, [(jobs[i].req, seeds[i]) for i in part])):
+                    rgbs[i] = rgb
+        with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
+            pngs = list(ex.map(encode_png, rgbs))
+        return list(zip(pngs, seeds))
 
     def close(self):
-        pipe = getattr(self, "pipe", None)
-        if pipe is not None:
-            pipe.drop_plans()
+        eng = getattr(self, "_engine", None)
+        if eng is None:
+            return
+        self._engine = None
+        if eng.release():                            # last worker on this engine: stop the dispatcher, free the graphs
+            if eng.batcher is not None:
+                eng.batcher.close()
+            pipe = getattr(self, "pipe", None)
+            if pipe is not None:
+                pipe.drop_plans()
+            if eng.first is not None:
+                eng.first.pipe = None
             self.pipe = None
 
     def __del__(self):
@@ -251,11 +364,12 @@ class HipLcmSDXLWorker(HipLcmWorker):
     def _text_bytes(self):
         return sum(e.weight_bytes() for e in self._enc)
 
-    def _conditioning(self, req, width, height, guidance):
-        h1 = self._enc[0].forward(self._tok[0]([req.prompt]), output="penultimate")
-        h2, pooled = self._enc[1].forward(self._tok[1]([req.prompt]), output="penultimate", pooled=True)
+    def _conditioning(self, reqs, width, height, guidance):
+        prompts = [r.prompt for r in reqs]
+        h1 = self._enc[0].forward(self._tok[0](prompts), output="penultimate")
+        h2, pooled = self._enc[1].forward(self._tok[1](prompts), output="penultimate", pooled=True)
         pe = torch.cat([h1, h2], dim=-1)
-        tids = torch.tensor([[float(height), float(width), 0.0, 0.0, float(height), float(width)]])
+        tids = torch.tensor([[float(height), float(width), 0.0, 0.0, float(height), float(width)]] * len(reqs))
         kw = dict(added=(pooled, tids))
         if guidance > 1.0 and not self.pipe.unet.has_cond:
             kw["negative_embeds"] = torch.zeros_like(pe)

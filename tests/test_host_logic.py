@@ -191,3 +191,55 @@ def test_style_registry_mirror():
         assert sd.path() == "/tmp/x.safetensors"
     finally:
         del os.environ["LCM_STYLE_PAPERCUT_PATH"]
+
+
+# ---- queue-level micro-batching: host logic only ------------------------------------
+def test_microbatcher_coalesces_by_key_and_keeps_order():
+    import threading, time
+    from sdlcm_amd.backends.batching import MicroBatcher
+    gate, calls = threading.Event(), []
+
+    def run(key, items):
+        if key == "block":
+            gate.wait(5)
+        calls.append((key, list(items)))
+        return [f"{key}:{it}" for it in items]
+
+    mb = MicroBatcher(run, max_batch=8)
+    first = mb.submit("block", 0)                 # occupies the dispatcher while the queue fills
+    time.sleep(0.05)
+    futs = [mb.submit("a", i) for i in range(5)] + [mb.submit("b", 9)] + [mb.submit("a", 5)]
+    gate.set()
+    assert first.result(5) == "block:0"
+    assert [f.result(5) for f in futs] == ["a:0", "a:1", "a:2", "a:3", "a:4", "b:9", "a:5"]
+    # 6 "a" jobs were waiting: plan batch sizes are 1/2/4/8 -> 4 first, then "b" is NOT starved behind the 2 left
+    assert calls[1] == ("a", [0, 1, 2, 3])
+    assert ("b", [9]) in calls and ("a", [4, 5]) in calls
+    assert mb.batches == [1, 4, 1, 2] or mb.batches == [1, 4, 2, 1]
+    mb.close()
+    import pytest
+    with pytest.raises(RuntimeError):
+        mb.submit("a", 1)
+
+
+def test_microbatcher_errors_reach_every_waiter_and_window():
+    import time
+    from sdlcm_amd.backends.batching import MicroBatcher
+
+    def run(key, items):
+        if key == "bad":
+            raise ValueError("boom")
+        return items
+
+    mb = MicroBatcher(run, max_batch=4, window_ms=200)
+    t0 = time.monotonic()
+    fa, fb = mb.submit("k", 1), mb.submit("k", 2)          # arrive within the window -> one pass of 2
+    assert fa.result(5) == 1 and fb.result(5) == 2
+    assert mb.batches == [2] and time.monotonic() - t0 >= 0.15
+    bad = [mb.submit("bad", i) for i in range(2)]
+    import pytest
+    for f in bad:
+        with pytest.raises(ValueError):
+            f.result(5)
+    assert mb.submit("k", 3).result(5) == 3                 # the dispatcher survives a failed pass
+    mb.close()

@@ -87,6 +87,60 @@ def test_random_seed(worker):
     assert 0 <= s1 < 100_000_000 and 0 <= s2 < 100_000_000 and s1 != s2 and p1 != p2
 
 
+def test_concurrent_callers_share_engine_and_coalesce(worker):
+    """the pool's threads each block in run_job on their own worker object; workers of one GPU share one
+    resident engine and queued jobs of equal (size, steps, guidance, style) run as batched passes.  Every caller
+    still gets the image of ITS seed (within fp16 batch-shape noise of the solo run), errors stay per caller."""
+    import io, threading
+    import numpy as np
+    from PIL import Image
+    from sdlcm_amd.backends.worker_factory import create_hip_worker
+    others = [create_hip_worker(worker_id=i) for i in (1, 2, 3)]
+    ws = [worker] + others
+    try:
+        assert all(w.pipe is worker.pipe for w in ws) and worker._engine.refs == 4
+        def dec(png):
+            return np.asarray(Image.open(io.BytesIO(png)).convert("RGB")).astype(int)
+        solo = {s: dec(worker.run_job(MockJob(MockGenerateRequest(prompt=f"prompt {s}", size="256x256", seed=s)))[0])
+                for s in range(8)}
+        n0 = len(worker._engine.batcher.batches)
+        got, errs = {}, []
+        def call(k):
+            try:
+                for s in (k, k + 4):
+                    png, seed = ws[k].run_job(MockJob(MockGenerateRequest(prompt=f"prompt {s}", size="256x256", seed=s)))
+                    got[seed] = dec(png)
+                if k == 3:
+                    with pytest.raises(RuntimeError):
+                        ws[k].run_job(MockJob(MockGenerateRequest(prompt="x", size="bogus", seed=1)))
+            except BaseException as e:      # noqa
+                errs.append(e)
+        th = [threading.Thread(target=call, args=(k,)) for k in range(4)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        assert not errs, errs
+        assert sorted(got) == list(range(8))
+        for s in range(8):
+            d = np.abs(got[s] - solo[s])
+            assert d.max() <= 3, (s, d.max())
+            assert all(np.abs(got[s] - solo[o]).mean() > 1.0 for o in range(8) if o != s)   # not somebody else's image
+        sizes = worker._engine.batcher.batches[n0:]
+        assert sum(sizes) == 8 and len(sizes) < 8, sizes          # at least one pass was a real batch
+        # run_jobs: explicit batched entry, mixed keys, results in job order
+        jobs = [MockJob(MockGenerateRequest(prompt=f"prompt {s}", size="256x256" if s != 2 else "128x128", seed=s)) for s in range(5)]
+        res = worker.run_jobs(jobs)
+        assert [r[1] for r in res] == list(range(5))
+        assert dec(res[2][0]).shape == (128, 128, 3)
+        for s in (0, 1, 3, 4):
+            assert np.abs(dec(res[s][0]) - solo[s]).max() <= 3
+    finally:
+        for w in others:
+            w.close()
+    assert worker._engine.refs == 1 and worker.pipe is not None
+    png, _ = worker.run_job(MockJob(MockGenerateRequest(prompt="prompt 0", size="256x256", seed=0)))
+    assert np.abs(dec(png) - solo[0]).max() == 0
+
+
 def test_sdxl_worker_contract():
     """DiffusersSDXLCudaWorker's behavioural contract (tests/test_sdxl_worker.py in the reference) on the SDXL-family HIP
     worker with synthetic full-size SDXL weights: (bytes,int), PNG, seed echo, determinism, 512-byte latents, CFG path."""

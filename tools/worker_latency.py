@@ -31,11 +31,37 @@ for lvl in (6, 1):
     ts, tp = [], []
     for i in range(20):
         t0 = time.perf_counter()
-        out, seed = w._generate(Job(Req(seed=100 + i)))
+        (rgb, _), seed = w._submit(Job(Req(seed=100 + i)))
         t1 = time.perf_counter()
-        png = hip_worker.encode_png(out["rgb"][0])
+        png = hip_worker.encode_png(rgb)
         t2 = time.perf_counter()
         ts.append((t1 - t0) * 1e3); tp.append((t2 - t1) * 1e3)
     print(f"png level {lvl}: generate (CLIP + noise draw + H2D + graph + D2H) p50 {statistics.median(ts):.1f} ms, "
           f"PNG encode p50 {statistics.median(tp):.1f} ms ({len(png) / 1e3:.0f} KB), run_job p50 {statistics.median([a + b for a, b in zip(ts, tp)]):.1f} ms")
+
+# ---- loaded case: N pool threads, one worker object each (as backends/worker_pool.py creates them), all
+# attached to the one resident engine; jobs queued behind a running pass coalesce into batched passes.
+import threading
+for nthreads in (1, 2, 4, 8, 16):
+    ws = [w] + [create_hip_worker(worker_id=i) for i in range(1, nthreads)]
+    per = 24
+    lat = [[] for _ in ws]
+    def loop(k):
+        for i in range(per):
+            t0 = time.perf_counter()
+            ws[k].run_job(Job(Req(seed=1000 * k + i)))
+            lat[k].append((time.perf_counter() - t0) * 1e3)
+    for k in range(len(ws)):
+        ws[k].run_job(Job(Req(seed=k)))
+    n0 = len(w._engine.batcher.batches) if w._engine.batcher else 0
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=loop, args=(k,)) for k in range(len(ws))]
+    [t.start() for t in th]; [t.join() for t in th]
+    dt = time.perf_counter() - t0
+    allp = sorted(x for l in lat for x in l)
+    bs = w._engine.batcher.batches[n0:] if w._engine.batcher else []
+    print(f"{nthreads:2d} callers: {nthreads * per / dt:6.1f} img/s  run_job p50 {allp[len(allp) // 2]:.1f} ms p95 {allp[int(len(allp) * 0.95)]:.1f} ms  "
+          f"passes {len(bs)} mean batch {sum(bs) / max(1, len(bs)):.2f}", flush=True)
+    for x in ws[1:]:
+        x.close()
 w.close()
