@@ -85,7 +85,11 @@ int lcm_gemm_tile_config(int M, int N, int batch);
 
 /* ---- 3x3 convolution, padding 1 (ResnetBlock2D.conv1/conv2, Downsample2D, Upsample2D.conv) ----
  * implicit GEMM over K = 9*Cin on MFMA; in: [B,Hin,Win,Cin]; stride 1|2; ups=1 reads the input through a
- * nearest-2x upsample (F.interpolate(scale_factor=2) fused into the loader).  Epilogue as lcm_gemm_f16.
+ * nearest-2x upsample (F.interpolate(scale_factor=2) fused into the loader).  ups=2 computes the same
+ * Upsample2D (interpolate -> conv) as four 2x2 PHASE convolutions on the low-resolution input -- output pixel
+ * (2y+py, 2x+px) only sees input rows {y-1+py, y+py} / columns {x-1+px, x+px} -- with W the phase-packed weights
+ * [4 = py*2+px][Cout][2][2][Cin] (3x3 taps that land on one input pixel pre-summed): 16 instead of 36 multiply-adds
+ * per output element and input channel.  Epilogue as lcm_gemm_f16.
  * Preconditions: Cin % 64 == 0, Cout % 64 == 0.
  */
 int lcm_conv3x3_f16(const void* in, const void* W, const void* bias,
@@ -97,7 +101,8 @@ int lcm_conv3x3_f16(const void* in, const void* W, const void* bias,
  * LDS-halo implicit GEMM (csrc/conv_halo.hip).  Input = channel concat [in | in2] (in2 NULL: single source; fused
  * torch.cat of the skip).  gn_scale/gn_shift: fp32 [B][C1+C2] from lcm_groupnorm_affine_f16 (NULL: plain conv);
  * silu=1 applies SiLU after the affine; zero padding is applied AFTER the normalisation, as in the reference
- * graph.  ups=1 reads the (raw) input through a nearest-2x upsample.  Epilogue as lcm_gemm_f16.
+ * graph.  ups=1 reads the (raw) input through a nearest-2x upsample; ups=2 as in lcm_conv3x3_f16 (gn_scale must be NULL).
+ * Epilogue as lcm_gemm_f16.
  * Preconditions: C1, C2, Cout multiples of 64.
  */
 int lcm_conv3x3_gn_f16(const void* in, int C1, const void* in2, int C2, const void* gn_scale, const void* gn_shift,

@@ -35,7 +35,8 @@ def _candidates(key, meta, ws_bytes):
     out = []
     for bm, bn in tiles:
         ntile = -(-M // bm) * (N // bn) * (aux if kind == 0 else 1)
-        units = (K // 576) if meta["halo"] else nk            # halo conv splits over 64-channel chunks
+        taps = 4 if meta.get("phases", 1) == 4 else 9         # phase-decomposed upsample conv: K = 4 * Cin
+        units = (K // (64 * taps)) if meta["halo"] else nk    # halo conv splits over 64-channel chunks
         splits = [1]
         if meta["splittable"]:
             for s in (2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 24, 32):

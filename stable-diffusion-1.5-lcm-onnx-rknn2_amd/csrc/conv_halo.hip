@@ -13,6 +13,12 @@
 // With XFORM the halo goes through registers: y = silu(x * scale[b][c] + shift[b][c]) (the GroupNorm affine
 // folded per (image, channel)) is applied once per staged element -- 1.4x per element per n-tile instead of
 // 9x -- and the normalised tensor is never written to HBM.
+// PH = 1: "nearest-2x upsample -> conv3x3" evaluated as four 2x2 PHASE convolutions on the low-resolution input:
+// output pixel (2y+py, 2x+px) only ever sees input rows {y-1+py, y+py} and columns {x-1+px, x+px}, with the 3x3 taps
+// that land on the same input pixel pre-summed at pack time (packing.pack_conv3x3_up2) -- 16 instead of 36
+// multiply-adds per output and input channel.  The workgroup then owns a TH x TW patch of INPUT pixels and one
+// phase (the 4 phases of a patch are adjacent tiles, so they share the halo in L2); weights are
+// [phase][Cout][2][2][Cin].
 // Single-buffered LDS (<= 40 KiB): 4 workgroups per CU cover the staging latency (measured faster than a
 // deeper pipeline at 2 workgroups per CU for the large grids this kernel is used on).
 // Wave layout, MFMA (16x16x32 f16, weights as the A operand) and epilogue are those of igemm.hip.
@@ -30,8 +36,9 @@ struct HaloParams {
 
 static __device__ __attribute__((aligned(256))) half_t g_zero_page_h[128];
 
-template <int TH, int TW, int BN, int XFORM>
+template <int TH, int TW, int BN, int XFORM, int PH>
 __global__ __launch_bounds__(256, 3) void conv_halo_kernel(HaloParams hp) {
+    constexpr int NT = PH ? 4 : 9;
     constexpr int BM = TH * TW;
     constexpr int TM = BM / 32, TN = BN / 32, RW = BN / 32;
     constexpr int HWD = TW + 2, HROWS = (TH + 2) * HWD, HROWS_PAD = (HROWS + 7) / 8 * 8;
@@ -46,7 +53,10 @@ __global__ __launch_bounds__(256, 3) void conv_halo_kernel(HaloParams hp) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 1, wn = wave >> 1;
     const int tile = xcd_remap(blockIdx.x, p.mtiles * p.ntiles);
-    const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
+    const int mt4 = tile / p.ntiles, nt = tile - mt4 * p.ntiles;
+    const int phase = PH ? (mt4 & 3) : 0, mt = PH ? (mt4 >> 2) : mt4;
+    const int py = phase >> 1, px = phase & 1;
+    const int IH = PH ? p.Hin : hp.H, IW = PH ? p.Win : hp.W;      // image the halo is cut from
     const int per_img = hp.tiles_y * hp.tiles_x;
     const int bimg = mt / per_img, tr = mt - bimg * per_img;
     const int ty = tr / hp.tiles_x, tx = tr - ty * hp.tiles_x;
@@ -63,8 +73,8 @@ __global__ __launch_bounds__(256, 3) void conv_halo_kernel(HaloParams hp) {
         const int hr = v >> 3;
         const int hy = hr / HWD, hx = hr - hy * HWD;
         int ly = y0 - 1 + hy, lx = x0 - 1 + hx;
-        const bool ok = hr < HROWS && ly >= 0 && ly < hp.H && lx >= 0 && lx < hp.W;
-        if (p.ups) { ly >>= 1; lx >>= 1; }
+        const bool ok = hr < HROWS && ly >= 0 && ly < IH && lx >= 0 && lx < IW;
+        if (!PH && p.ups) { ly >>= 1; lx >>= 1; }
         h_pix[i] = ok ? (bimg * p.Hin + ly) * p.Win + lx : -1;
     }
     // glds path: LDS position is lane-linear (v*16) and the SOURCE chunk is swizzled;
@@ -73,7 +83,7 @@ __global__ __launch_bounds__(256, 3) void conv_halo_kernel(HaloParams hp) {
     const int x_lds0 = (tid >> 3) * 128 + ((pos ^ ((tid >> 3) & 7)) << 4);
     const int w_row0 = tid >> 3;
     const int w_schunk = (pos ^ (w_row0 & 7)) * 8;
-    const half_t* wptr = p.W + (long long)(n_base + w_row0) * p.K + w_schunk;
+    const half_t* wptr = p.W + (PH ? (long long)phase * p.N * p.K : 0ll) + (long long)(n_base + w_row0) * p.K + w_schunk;
 
     // ---- per-lane fragment row bases ----
     const int frow = lane & 15, fq = lane >> 4;
@@ -99,7 +109,7 @@ __global__ __launch_bounds__(256, 3) void conv_halo_kernel(HaloParams hp) {
         const half_t* src_base = second ? p.A2 : p.A;
         const int src_ld = second ? C2 : hp.C1;
         const int src_c = second ? cb - hp.C1 : cb;
-        for (int tap = 0; tap < 9; ++tap) {
+        for (int tap = 0; tap < NT; ++tap) {
             if (!first) __syncthreads();          // all waves finished reading the W tile (and the halo when tap == 0)
             first = false;
             if (tap == 0) {
@@ -156,7 +166,7 @@ __global__ __launch_bounds__(256, 3) void conv_halo_kernel(HaloParams hp) {
             }
             __syncthreads();      // drains the LDS-DMA (vmcnt(0)) and the ds_writes, then barrier
 
-            const int dy = tap / 3, dx = tap - dy * 3;
+            const int dy = PH ? (tap >> 1) + py : tap / 3, dx = PH ? (tap & 1) + px : tap - (tap / 3) * 3;
             const int tapoff = dy * HWD + dx;
             const char* wsr = wsm + (wn * (BN / 2)) * 128;
 #pragma unroll
@@ -187,9 +197,9 @@ __global__ __launch_bounds__(256, 3) void conv_halo_kernel(HaloParams hp) {
     for (int b = 0; b < TM; ++b) {
         const int q = (wm * TM + b) * 16 + frow;
         const int y = y0 + q / TW, x = x0 + q % TW;
-        m_of[b] = (y < hp.H && x < hp.W) ? (bimg * hp.H + y) * hp.W + x : -1;
+        m_of[b] = (y < IH && x < IW) ? (PH ? (bimg * hp.H + 2 * y + py) * hp.W + 2 * x + px : (bimg * hp.H + y) * hp.W + x) : -1;
     }
-    igemm_epilogue<BM, BN>(p, acc, m_of, n_base + wn * (BN / 2), fq, 0, mt * 2 + wm);
+    igemm_epilogue<BM, BN>(p, acc, m_of, n_base + wn * (BN / 2), fq, 0, mt4 * 2 + wm);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -203,8 +213,9 @@ __device__ __forceinline__ void halo_wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int TH, int TW, int BN, int WS>
+template <int TH, int TW, int BN, int WS, int PH>
 __global__ __launch_bounds__(256, 2) void conv_halo_pipe_kernel(HaloParams hp) {
+    constexpr int NT = PH ? 4 : 9;
     constexpr int BM = TH * TW;
     constexpr int TM = BM / 32, TN = BN / 32, RW = BN / 32;
     constexpr int HWD = TW + 2, HROWS = (TH + 2) * HWD, HROWS_PAD = (HROWS + 7) / 8 * 8;
@@ -219,7 +230,10 @@ __global__ __launch_bounds__(256, 2) void conv_halo_pipe_kernel(HaloParams hp) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 1, wn = wave >> 1;
     const int tile = xcd_remap(blockIdx.x, p.mtiles * p.ntiles);
-    const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
+    const int mt4 = tile / p.ntiles, nt = tile - mt4 * p.ntiles;
+    const int phase = PH ? (mt4 & 3) : 0, mt = PH ? (mt4 >> 2) : mt4;
+    const int py = phase >> 1, px = phase & 1;
+    const int IH = PH ? p.Hin : hp.H, IW = PH ? p.Win : hp.W;      // image the halo is cut from
     const int per_img = hp.tiles_y * hp.tiles_x;
     const int bimg = mt / per_img, tr = mt - bimg * per_img;
     const int ty = tr / hp.tiles_x, tx = tr - ty * hp.tiles_x;
@@ -234,13 +248,13 @@ __global__ __launch_bounds__(256, 2) void conv_halo_pipe_kernel(HaloParams hp) {
         const int hr = (tid + 256 * i) >> 3;
         const int hy = hr / HWD, hx = hr - hy * HWD;
         int ly = y0 - 1 + hy, lx = x0 - 1 + hx;
-        const bool ok = hr < HROWS && ly >= 0 && ly < hp.H && lx >= 0 && lx < hp.W;
-        if (p.ups) { ly >>= 1; lx >>= 1; }
+        const bool ok = hr < HROWS && ly >= 0 && ly < IH && lx >= 0 && lx < IW;
+        if (!PH && p.ups) { ly >>= 1; lx >>= 1; }
         h_pix[i] = ok ? (bimg * p.Hin + ly) * p.Win + lx : -1;
     }
     const int w_row0 = tid >> 3;
     const int w_schunk = (pos ^ (w_row0 & 7)) * 8;
-    const half_t* wptr = p.W + (long long)(n_base + w_row0) * p.K + w_schunk;
+    const half_t* wptr = p.W + (PH ? (long long)phase * p.N * p.K : 0ll) + (long long)(n_base + w_row0) * p.K + w_schunk;
 
     const int frow = lane & 15, fq = lane >> 4;
     const int q0 = wm * TM * 16 + frow;
@@ -256,7 +270,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_pipe_kernel(HaloParams hp) {
     const int nchunks = p.Cin >> 6;
     const int c_begin = (int)((long long)blockIdx.y * nchunks / p.splits);
     const int c_end = (int)((long long)(blockIdx.y + 1) * nchunks / p.splits);
-    const int T = (c_end - c_begin) * 9;
+    const int T = (c_end - c_begin) * NT;
 
     auto issue_halo = [&](int c64, int hb) {
         const int cb = c64 << 6;
@@ -278,7 +292,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_pipe_kernel(HaloParams hp) {
         }
     };
     auto issue_w = [&](int t, int wb) {     // t = flattened (chunk, tap) step
-        const int c64 = c_begin + t / 9, tap = t - (t / 9) * 9;
+        const int c64 = c_begin + t / NT, tap = t - (t / NT) * NT;
         const half_t* wsrc = wptr + (long long)tap * p.Cin + (c64 << 6);
         char* wsm = wsm0 + wb * WBYTES;
 #pragma unroll
@@ -295,7 +309,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_pipe_kernel(HaloParams hp) {
 
     int wb = 0;
     for (int t = 0; t < T; ++t) {
-        const int chunk = t / 9, tap = t - chunk * 9;
+        const int chunk = t / NT, tap = t - chunk * NT;
         // W(t) (and, being older, this chunk's halo) must have landed; min(WS-2, T-1-t) newer slices may stay in flight
         const int newer = T - 1 - t;
         if (WS >= 4 && newer >= 2) halo_wait_vmcnt<(WS >= 4 ? 2 : 0) * RW>();
@@ -306,7 +320,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_pipe_kernel(HaloParams hp) {
         if (tap == 0 && c_begin + chunk + 1 < c_end) issue_halo(c_begin + chunk + 1, (chunk + 1) & 1);
 
         const char* xs = xs0 + (chunk & 1) * XBYTES;
-        const int dy = tap / 3, dx = tap - dy * 3;
+        const int dy = PH ? (tap >> 1) + py : tap / 3, dx = PH ? (tap & 1) + px : tap - (tap / 3) * 3;
         const int tapoff = dy * HWD + dx;
         const char* wsr = wsm0 + wb * WBYTES + (wn * (BN / 2)) * 128;
 #pragma unroll
@@ -337,9 +351,9 @@ __global__ __launch_bounds__(256, 2) void conv_halo_pipe_kernel(HaloParams hp) {
     for (int b = 0; b < TM; ++b) {
         const int q = (wm * TM + b) * 16 + frow;
         const int y = y0 + q / TW, x = x0 + q % TW;
-        m_of[b] = (y < hp.H && x < hp.W) ? (bimg * hp.H + y) * hp.W + x : -1;
+        m_of[b] = (y < IH && x < IW) ? (PH ? (bimg * hp.H + 2 * y + py) * hp.W + 2 * x + px : (bimg * hp.H + y) * hp.W + x) : -1;
     }
-    igemm_epilogue<BM, BN>(p, acc, m_of, n_base + wn * (BN / 2), fq, 0, mt * 2 + wm);
+    igemm_epilogue<BM, BN>(p, acc, m_of, n_base + wn * (BN / 2), fq, 0, mt4 * 2 + wm);
 }
 
 // split-K combine kernel lives in igemm.hip
@@ -353,11 +367,11 @@ static int g_halo_pipe_below = 768;      // workgroup count under which the pipe
 
 extern "C" int lcm_set_halo_pipe_threshold(int wgs) { g_halo_pipe_below = wgs; return LCM_OK; }
 
-template <int TH, int TW, int BN, int XFORM>
+template <int TH, int TW, int BN, int XFORM, int PH>
 static void launch_halo(HaloParams& hp, hipStream_t s) {
     constexpr int HROWS_PAD = ((TH + 2) * (TW + 2) + 7) / 8 * 8;
-    hp.tiles_y = (hp.H + TH - 1) / TH;
-    hp.tiles_x = (hp.W + TW - 1) / TW;
+    hp.tiles_y = ((PH ? hp.g.Hin : hp.H) + TH - 1) / TH;
+    hp.tiles_x = ((PH ? hp.g.Win : hp.W) + TW - 1) / TW;
     hp.g.ntiles = hp.g.N / BN;
     dim3 grid(hp.g.mtiles * hp.g.ntiles, hp.g.splits, 1);
     if (!XFORM && (long long)grid.x * grid.y < g_halo_pipe_below) {
@@ -365,29 +379,31 @@ static void launch_halo(HaloParams& hp, hipStream_t s) {
         constexpr int smem = 2 * HROWS_PAD * 128 + WS * BN * 128;
         static bool attr_set = false;
         if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_pipe_kernel<TH, TW, BN, WS>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_pipe_kernel<TH, TW, BN, WS, PH>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem);
             attr_set = true;
         }
         char nm[64];
-        snprintf(nm, sizeof(nm), "conv_halo_pipe_kernel<%d, %d, %d, %d>%s", TH, TW, BN, WS, hp.g.splits > 1 ? " +splitk" : "");
+        snprintf(nm, sizeof(nm), "conv_halo_pipe_kernel<%d, %d, %d, %d, %d>%s", TH, TW, BN, WS, PH, hp.g.splits > 1 ? " +splitk" : "");
         lcm_prof_start(nm, s);
-        hipLaunchKernelGGL((conv_halo_pipe_kernel<TH, TW, BN, WS>), grid, dim3(256), smem, s, hp);
+        hipLaunchKernelGGL((conv_halo_pipe_kernel<TH, TW, BN, WS, PH>), grid, dim3(256), smem, s, hp);
         lcm_prof_stop(s);
         return;
     }
     constexpr int smem = HROWS_PAD * 128 + BN * 128;
     char nm[64];
-    snprintf(nm, sizeof(nm), "conv_halo_kernel<%d, %d, %d, %d>%s", TH, TW, BN, XFORM, hp.g.splits > 1 ? " +splitk" : "");
+    snprintf(nm, sizeof(nm), "conv_halo_kernel<%d, %d, %d, %d, %d>%s", TH, TW, BN, XFORM, PH, hp.g.splits > 1 ? " +splitk" : "");
     lcm_prof_start(nm, s);
-    hipLaunchKernelGGL((conv_halo_kernel<TH, TW, BN, XFORM>), grid, dim3(256), smem, s, hp);
+    hipLaunchKernelGGL((conv_halo_kernel<TH, TW, BN, XFORM, PH>), grid, dim3(256), smem, s, hp);
     lcm_prof_stop(s);
 }
 
 // returns 0 when launched, 1 when the shape is not handled here (caller falls back to the row-gather igemm)
 int lcm_conv_halo_launch(HaloParams& hp, int B, hipStream_t s, int* slabs_per_image) {
     IgemmParams& p = hp.g;
-    const int TW = (hp.W % 16 == 0 || hp.W > 16) ? 16 : 8;
+    const bool ph = p.ups == 2;                      // phase-decomposed upsample conv: tiles walk the INPUT image, x4 phases
+    const int IH = ph ? p.Hin : hp.H, IW = ph ? p.Win : hp.W, PHM = ph ? 4 : 1;
+    const int TW = (IW % 16 == 0 || IW > 16) ? 16 : 8;
     int target, max_splits, min_wgs;
     lcm_tuning(&target, &max_splits, &min_wgs);
     long long ws_bytes = 0;
@@ -402,7 +418,7 @@ int lcm_conv_halo_launch(HaloParams& hp, int B, hipStream_t s, int* slabs_per_im
         if (p.N % cbn) continue;
         if (TW == 8 && cbm == 128) continue;
         const int th = cbm / TW;
-        const long long mt = (long long)B * ((hp.H + th - 1) / th) * ((hp.W + TW - 1) / TW);
+        const long long mt = (long long)B * ((IH + th - 1) / th) * ((IW + TW - 1) / TW) * PHM;
         // skip tiles that would be mostly padding
         if ((long long)mt * cbm > 2ll * p.M && cbm == 128) continue;
         const long long tiles = mt * (p.N / cbn);
@@ -427,7 +443,7 @@ int lcm_conv_halo_launch(HaloParams& hp, int B, hipStream_t s, int* slabs_per_im
     }
     if (!bm) return 1;
     const int th = bm / TW;
-    p.mtiles = B * ((hp.H + th - 1) / th) * ((hp.W + TW - 1) / TW);
+    p.mtiles = B * ((IH + th - 1) / th) * ((IW + TW - 1) / TW) * PHM;
     p.splits = splits;
     if (p.stats) {   // fused GroupNorm statistics of the output
         if (p.N > 2048) p.stats = nullptr;
@@ -440,9 +456,12 @@ int lcm_conv_halo_launch(HaloParams& hp, int B, hipStream_t s, int* slabs_per_im
     }
     if (splits > 1 && p.reduce_rows <= 0) p.reduce_rows = lcm_reduce_rows(p.M, 0);
     const bool xf = hp.gn_scale != nullptr;
+    if (ph && xf) return 1;
 #define HALO_CASE(TH_, TW_, BN_)                                                           \
     if (th == TH_ && TW == TW_ && bn == BN_) {                                             \
-        if (xf) launch_halo<TH_, TW_, BN_, 1>(hp, s); else launch_halo<TH_, TW_, BN_, 0>(hp, s); \
+        if (ph) launch_halo<TH_, TW_, BN_, 0, 1>(hp, s);                                   \
+        else if (xf) launch_halo<TH_, TW_, BN_, 1, 0>(hp, s);                              \
+        else launch_halo<TH_, TW_, BN_, 0, 0>(hp, s);                                      \
     } else
     HALO_CASE(8, 16, 128) HALO_CASE(8, 16, 64) HALO_CASE(4, 16, 128) HALO_CASE(4, 16, 64)
     HALO_CASE(8, 8, 128) HALO_CASE(8, 8, 64) { return 1; }

@@ -697,10 +697,11 @@ extern "C" int lcm_conv3x3_gn_f16(const void* in, int C1, const void* in2, int C
     IgemmParams& p = hp.g;
     p.A = (const half_t*)in; p.A2 = (const half_t*)in2; p.W = (const half_t*)W; p.bias = (const half_t*)bias;
     p.rowadd = (const half_t*)rowadd; p.res = (const half_t*)res; p.out = (half_t*)out;
+    LCM_REQUIRE(ups >= 0 && ups <= 2 && !(ups == 2 && gn_scale), "conv3x3_gn: ups=%d (2 = phase-packed weights, no fused GroupNorm)", ups);
     p.Hin = Hin; p.Win = Win; p.Cin = Cin; p.stride = 1; p.ups = ups;
     hp.H = ups ? 2 * Hin : Hin; hp.W = ups ? 2 * Win : Win;
     p.Hout = hp.H; p.Wout = hp.W;
-    p.M = B * hp.H * hp.W; p.N = Cout; p.K = 9 * Cin;
+    p.M = B * hp.H * hp.W; p.N = Cout; p.K = (ups == 2 ? 4 : 9) * Cin;
     p.ldo = Cout; p.ldr = Cout; p.ld_rowadd = ld_rowadd; p.rows_per_batch = hp.H * hp.W;
     p.epi = 0; p.out_scale = 1.0f; p.splits = 1;
     hp.C1 = C1; hp.gn_scale = (const float*)gn_scale; hp.gn_shift = (const float*)gn_shift; hp.silu = silu;
@@ -724,7 +725,7 @@ extern "C" int lcm_conv3x3_f16(const void* in, const void* W, const void* bias,
     LCM_REQUIRE(stride == 1 || stride == 2, "conv3x3: stride %d", stride);
     LCM_REQUIRE(!(ups && stride != 1), "conv3x3: upsample needs stride 1");
     if (rowadd) LCM_REQUIRE(ld_rowadd % 4 == 0, "conv3x3: ld_rowadd misaligned");
-    if (stride == 1 && g_conv_impl == 1)
+    if (stride == 1 && (g_conv_impl == 1 || ups == 2))
         return lcm_conv3x3_gn_f16(in, Cin, nullptr, 0, nullptr, nullptr, 0, W, bias, rowadd, ld_rowadd, res, out, B, Hin, Win,
                                   Cout, ups, stats_out, slabs_per_image, stream);
     const int Hl = ups ? 2 * Hin : Hin, Wl = ups ? 2 * Win : Win;

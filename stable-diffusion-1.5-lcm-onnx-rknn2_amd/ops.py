@@ -117,11 +117,13 @@ def conv3x3(x, w, out, B, H, W, Cin, Cout, *, bias=None, rowadd=None, res=None, 
     sbuf, sp = _stats_args(stats)
     Ho, Wo = ((2 * H, 2 * W) if ups else ((H + 1) // 2, (W + 1) // 2) if stride == 2 else (H, W))
     Mo = B * Ho * Wo
+    taps = 4 if ups == 2 else 9                 # ups=2: phase-packed weights (packing.pack_conv3x3_up2), 4 taps per output
     if RECORD is not None:
         kw = dict(bias=bias, rowadd=rowadd, res=res, stride=stride, ups=ups, stats=stats)
-        key = (1, Mo, Cout, 9 * Cin, 1) if stride == 2 else (2, Mo, Cout, 9 * Cin, (Wo << 1))
-        RECORD.append((key, dict(splittable=True, halo=stride == 1, W=Wo), lambda: conv3x3(x, w, out, B, H, W, Cin, Cout, **kw)))
-    with _Timed("conv3x3", tile_config(Mo, Cout) if PROFILE is not None else "", 2.0 * Mo * Cout * 9 * Cin,
+        key = (1, Mo, Cout, 9 * Cin, 1) if stride == 2 else (2, Mo, Cout, taps * Cin, (Wo << 1))
+        RECORD.append((key, dict(splittable=True, halo=stride == 1, W=(W if ups == 2 else Wo), phases=4 if ups == 2 else 1),
+                       lambda: conv3x3(x, w, out, B, H, W, Cin, Cout, **kw)))
+    with _Timed("conv3x3", tile_config(Mo, Cout) if PROFILE is not None else "", 2.0 * Mo * Cout * taps * Cin,
                 2.0 * (B * H * W * Cin + 9 * Cin * Cout + Mo * Cout)):
         rc = L.lcm_conv3x3_f16(_p(x), _p(w), _p(bias), _p(rowadd), rowadd.stride(0) if rowadd is not None else 0,
                                _p(res), _p(out), B, H, W, Cin, Cout, stride, ups, sbuf,

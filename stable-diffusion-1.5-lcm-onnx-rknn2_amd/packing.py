@@ -15,6 +15,29 @@ def pack_conv3x3(w: torch.Tensor) -> torch.Tensor:
     return w.permute(0, 2, 3, 1).contiguous().reshape(w.shape[0], -1)
 
 
+# taps of the 3x3 kernel that read the same low-resolution pixel after a nearest-2x upsample, per (phase, 2x2 tap):
+# even outputs (phase 0) see rows {y-1: k0, y: k1+k2}; odd outputs (phase 1) see rows {y: k0+k1, y+1: k2}
+_UP2_TAPS = (((0,), (1, 2)), ((0, 1), (2,)))
+
+
+def pack_conv3x3_up2(w: torch.Tensor) -> torch.Tensor:
+    """Upsample2D = F.interpolate(scale_factor=2, mode="nearest") -> conv3x3 as four 2x2 phase convolutions on the
+    low-resolution input: -> [4 (py*2+px) * Cout, 2*2*Cin] with the coinciding 3x3 taps summed in fp32."""
+    Cout, Cin = w.shape[:2]
+    wf = w.float()
+    out = torch.empty(4, Cout, 2, 2, Cin, dtype=torch.float32)
+    for py in range(2):
+        for px in range(2):
+            for dy in range(2):
+                for dx in range(2):
+                    acc = torch.zeros(Cout, Cin)
+                    for ky in _UP2_TAPS[py][dy]:
+                        for kx in _UP2_TAPS[px][dx]:
+                            acc += wf[:, :, ky, kx]
+                    out[py * 2 + px, :, dy, dx, :] = acc
+    return out.reshape(4 * Cout, 4 * Cin).to(w.dtype)
+
+
 def pack_conv1x1(w: torch.Tensor) -> torch.Tensor:
     return w.reshape(w.shape[0], -1).contiguous()
 

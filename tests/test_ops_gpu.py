@@ -250,6 +250,46 @@ def test_conv_halo_pipelined_variant_is_bit_identical(B, H, W, Cin, Cout, ups, s
     close(from_nhwc(outs[1], B, Ho, Wo), ref, what="conv halo pipelined")
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,splitk", [(2, 12, 20, 128, 192, False), (1, 9, 7, 64, 64, False), (1, 6, 10, 192, 128, False),
+                                                  (1, 16, 16, 1280, 1280, True), (2, 32, 32, 640, 640, True),
+                                                  (1, 1, 1, 128, 64, False), (1, 64, 48, 128, 128, False)])
+def test_conv_upsample_phase_decomposition(B, H, W, Cin, Cout, splitk):
+    """Upsample2D (F.interpolate nearest 2x -> conv3x3) as four 2x2 phase convolutions on the low-resolution input
+    (ups=2, packing.pack_conv3x3_up2): same result as the reference op order, pipelined == single-buffer bitwise,
+    fused GroupNorm statistics of the output intact."""
+    from sdlcm_amd.packing import pack_conv3x3_up2
+    x = to_nhwc(rnd(B, Cin, H, W, seed=1)).to(DEV)
+    w4 = rnd(Cout, Cin, 3, 3, seed=2, scale=(9 * Cin) ** -0.5)
+    wp = pack_conv3x3_up2(w4).to(DEV)
+    b = rnd(Cout, seed=3).to(DEV)
+    Ho, Wo = 2 * H, 2 * W
+    ws = torch.empty(16 << 20, dtype=torch.float32, device=DEV)
+    ops.set_workspace(ws if splitk else None)
+    outs, sts = [], []
+    try:
+        for thr in (0, 1 << 30):
+            ops.set_halo_pipe_threshold(thr)
+            o = torch.empty(B * Ho * Wo, Cout, dtype=torch.float16, device=DEV)
+            st = ops.Stats(torch.zeros(ops.stats_floats(B * Ho * Wo, Cout), dtype=torch.float32, device=DEV))
+            ops.conv3x3(x, wp, o, B, H, W, Cin, Cout, bias=b, ups=2, stats=st)
+            outs.append(o)
+            sts.append(st)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_halo_pipe_threshold(768)
+        ops.set_workspace(None)
+    assert torch.equal(outs[0], outs[1])
+    xin = F.interpolate(from_nhwc(x.cpu().float(), B, H, W), scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(xin, w4.float(), b.cpu().float(), padding=1)
+    close(from_nhwc(outs[1], B, Ho, Wo), ref, what="phase-decomposed upsample conv")
+    if Cout % 32 == 0 and sts[1].P > 0:
+        gamma, beta = (1 + 0.1 * rnd(Cout, seed=6).float()).half(), rnd(Cout, seed=7, scale=0.1)
+        y = torch.empty(B * Ho * Wo, Cout, dtype=torch.float16, device=DEV)
+        gws = torch.empty(ops.groupnorm_ws_bytes(B, Ho * Wo, Cout) // 4 + 16, dtype=torch.float32, device=DEV)
+        ops.groupnorm_from_stats(outs[1], gamma.to(DEV), beta.to(DEV), y, B, Ho * Wo, Cout, sts[1], gws)
+        close(y, _ref_gn(outs[1].cpu(), B, Ho * Wo, Cout, gamma, beta, 1e-5, True), what="gn from phase-conv statistics")
+
+
 def test_conv_halo_matches_row_gather_igemm():
     """The two 3x3 implementations agree to fp32 summation-order noise on a plain conv (border + m-tail)."""
     B, H, W, Cin, Cout = 2, 20, 28, 192, 128
