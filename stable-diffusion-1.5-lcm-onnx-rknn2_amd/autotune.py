@@ -22,8 +22,10 @@ def _candidates(key, meta, ws_bytes):
     nk = K // 64
     tiles = []
     for bm in (128, 64):
-        for bn in (128, 64):
+        for bn in (160, 128, 64):
             if N % bn:
+                continue
+            if bn == 160 and (kind == 1 or meta.get("geglu")):     # 160-wide tile: plain GEMM and halo conv only
                 continue
             if meta["halo"]:
                 tw = 16 if (meta["W"] % 16 == 0 or meta["W"] > 16) else 8

@@ -464,7 +464,7 @@ int lcm_conv_halo_launch(HaloParams& hp, int B, hipStream_t s, int* slabs_per_im
         else launch_halo<TH_, TW_, BN_, 0, 0>(hp, s);                                      \
     } else
     HALO_CASE(8, 16, 128) HALO_CASE(8, 16, 64) HALO_CASE(4, 16, 128) HALO_CASE(4, 16, 64)
-    HALO_CASE(8, 8, 128) HALO_CASE(8, 8, 64) { return 1; }
+    HALO_CASE(8, 8, 128) HALO_CASE(8, 8, 64) HALO_CASE(8, 16, 160) HALO_CASE(4, 16, 160) HALO_CASE(8, 8, 160) { return 1; }
 #undef HALO_CASE
     if (splits > 1) lcm_launch_splitk_reduce(p, s);
     return 0;

@@ -438,7 +438,7 @@ static std::map<std::tuple<int, int, int, int, int>, PlanVal> g_plans;
 static std::mutex g_plans_mu;
 
 extern "C" int lcm_plan_set(int kind, int M, int N, int K, int aux, int bm, int bn, int splits, int variant) {
-    if (!((bm == 128 || bm == 64) && (bn == 128 || bn == 64) && splits >= 1 && splits <= 64 && variant >= -1 && variant <= 4)) {
+    if (!((bm == 128 || bm == 64) && (bn == 128 || bn == 64 || bn == 160) && splits >= 1 && splits <= 64 && variant >= -1 && variant <= 4)) {
         lcm_set_error("plan_set: bad plan %dx%d splits %d variant %d", bm, bn, splits, variant);
         return LCM_EINVAL;
     }
@@ -615,7 +615,10 @@ static int launch_igemm(IgemmParams& p, int batch, hipStream_t s, int stats_hw =
     const long long wsb = p.ws ? g_ws_bytes[dev] : 0;
     TilePick t = pick_tile(p.M, p.N, p.K, batch, wsb, p.ws != nullptr && p.epi == 0);
     int variant = -1, pbm, pbn, psp, pv;
-    if (lcm_plan_get(MODE, p.M, p.N, p.K, batch, &pbm, &pbn, &psp, &pv) && p.N % pbn == 0) {
+    // the 160-wide tile (N = 320 / 640 / 960 ...: fewer L2->LDS bytes per FLOP than 64-wide) exists for the plain GEMM only;
+    // its 5 n-fragments per wave cannot carry the GEGLU value/gate pairing
+    if (lcm_plan_get(MODE, p.M, p.N, p.K, batch, &pbm, &pbn, &psp, &pv) && p.N % pbn == 0 &&
+        !(pbn == 160 && (MODE != 0 || p.epi == 1))) {
         if (psp > 1 && (p.epi != 0 || batch != 1 || (long long)psp * p.M * p.N * 4 > wsb || psp > (p.K >> 6))) psp = 1;
         t = {pbm, pbn, psp};
         variant = pv;
@@ -639,6 +642,8 @@ static int launch_igemm(IgemmParams& p, int batch, hipStream_t s, int stats_hw =
         case 128128: return launch_cfg<128, 128, MODE>(p, batch, t.splits, variant, s);
         case 128064: return launch_cfg<128, 64, MODE>(p, batch, t.splits, variant, s);
         case 64128: return launch_cfg<64, 128, MODE>(p, batch, t.splits, variant, s);
+        case 128160: if constexpr (MODE == 0) return launch_cfg<128, 160, MODE>(p, batch, t.splits, variant, s);
+        case 64160: if constexpr (MODE == 0) return launch_cfg<64, 160, MODE>(p, batch, t.splits, variant, s);
         default: return launch_cfg<64, 64, MODE>(p, batch, t.splits, variant, s);
     }
 }

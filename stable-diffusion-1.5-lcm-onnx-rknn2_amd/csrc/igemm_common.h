@@ -109,7 +109,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f4 (&acc)[B
                 }
             }
         }
-    } else {  // GEGLU: even n-tile = value rows, odd n-tile = gate rows (16-row interleave)
+    } else if constexpr (TN % 2 == 0) {  // GEGLU: even n-tile = value rows, odd n-tile = gate rows (16-row interleave)
 #pragma unroll
         for (int a = 0; a < TN; a += 2) {
             const int n = n_wave + a * 16 + fq * 4;      // packed row of the value

@@ -97,7 +97,7 @@ def gemm(a, w, out, *, bias=None, res=None, rowadd=None, rows_per_batch=0, a2=No
         kw = dict(bias=bias, res=res, rowadd=rowadd, rows_per_batch=rows_per_batch, a2=a2, epilogue=epilogue,
                   out_scale=out_scale, M=M, N=N, K=K, lda=lda, ldo=ldo, batch=batch, strideA=strideA, strideW=strideW,
                   strideO=strideO, stats=stats, stats_hw=stats_hw)
-        RECORD.append(((0, M, N, K, batch), dict(splittable=(epilogue == 0 and batch == 1), halo=False),
+        RECORD.append(((0, M, N, K, batch), dict(splittable=(epilogue == 0 and batch == 1), halo=False, geglu=(epilogue == 1)),
                        lambda: gemm(a, w, out, **kw)))
     with _Timed("gemm", tile_config(M, N, batch) if PROFILE is not None else "", 2.0 * M * N * K * batch,
                 2.0 * batch * (M * K + N * K + M * N)):

@@ -290,6 +290,56 @@ def test_conv_upsample_phase_decomposition(B, H, W, Cin, Cout, splitk):
         close(y, _ref_gn(outs[1].cpu(), B, Ho * Wo, Cout, gamma, beta, 1e-5, True), what="gn from phase-conv statistics")
 
 
+@pytest.mark.parametrize("variant", [-1, 1, 2, 4])
+def test_160_wide_tiles_gemm_and_conv(variant):
+    """The BN=160 tile (N = 320 / 640 / 960: 5 n-fragments per wave, fewer L2->LDS bytes per FLOP than 64-wide) is a
+    plan-table choice: forced here for GEMM (with residual, split-K, fused statistics) and the halo conv (plain,
+    pipelined, phase-decomposed upsample) against the torch ops."""
+    from sdlcm_amd.packing import pack_conv3x3_up2
+    ws = torch.empty(16 << 20, dtype=torch.float32, device=DEV)
+    ops.set_workspace(ws)
+    ops.set_kernel_variant(variant)
+    try:
+        for (M, N, K, bm, sp) in [(4096, 320, 320, 128, 1), (1000, 640, 1280, 128, 1), (256, 960, 1280, 64, 4), (8192, 320, 1280, 64, 1)]:
+            ops.plan_clear()
+            ops.plan_set(0, M, N, K, 1, bm, 160, sp)
+            a, w, b, r = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3), rnd(M, N, seed=4)
+            out = torch.empty(M, N, dtype=torch.float16, device=DEV)
+            st = ops.Stats(torch.zeros(ops.stats_floats(M, N), dtype=torch.float32, device=DEV))
+            hw = 256 if M % 256 == 0 else 0
+            ops.gemm(a.to(DEV), w.to(DEV), out, bias=b.to(DEV), res=r.to(DEV), stats=st if hw else None, stats_hw=hw)
+            close(out, F.linear(a.float(), w.float(), b.float()) + r.float(), what=f"gemm 160-wide {M}x{N}x{K}")
+            if hw and N % 32 == 0 and st.P > 0:
+                Bimg = M // hw
+                gamma, beta = (1 + 0.1 * rnd(N, seed=6).float()).half(), rnd(N, seed=7, scale=0.1)
+                y = torch.empty(M, N, dtype=torch.float16, device=DEV)
+                gws = torch.empty(ops.groupnorm_ws_bytes(Bimg, hw, N) // 4 + 16, dtype=torch.float32, device=DEV)
+                ops.groupnorm_from_stats(out, gamma.to(DEV), beta.to(DEV), y, Bimg, hw, N, st, gws)
+                close(y, _ref_gn(out.cpu(), Bimg, hw, N, gamma, beta, 1e-5, True), what="gn from 160-wide gemm statistics")
+        for (B, H, W, Cin, Cout, bm, sp, ups, thr) in [(2, 16, 16, 128, 320, 128, 1, 0, 0), (1, 12, 20, 192, 320, 64, 1, 0, 1 << 30),
+                                                       (1, 8, 8, 640, 640, 64, 5, 0, 1 << 30), (1, 16, 16, 128, 320, 128, 1, 2, 0),
+                                                       (2, 8, 8, 256, 320, 64, 2, 2, 1 << 30)]:
+            ops.plan_clear()
+            ops.set_halo_pipe_threshold(thr)
+            Ho, Wo = (2 * H, 2 * W) if ups else (H, W)
+            ops.plan_set(2, B * Ho * Wo, Cout, (4 if ups else 9) * Cin, Wo << 1, bm, 160, sp)
+            x = to_nhwc(rnd(B, Cin, H, W, seed=1)).to(DEV)
+            w4 = rnd(Cout, Cin, 3, 3, seed=2, scale=(9 * Cin) ** -0.5)
+            wk = (pack_conv3x3_up2(w4) if ups else pack3x3(w4)).to(DEV)
+            b = rnd(Cout, seed=3).to(DEV)
+            o = torch.empty(B * Ho * Wo, Cout, dtype=torch.float16, device=DEV)
+            ops.conv3x3(x, wk, o, B, H, W, Cin, Cout, bias=b, ups=ups)
+            xin = from_nhwc(x.cpu().float(), B, H, W)
+            if ups:
+                xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+            close(from_nhwc(o, B, Ho, Wo), F.conv2d(xin, w4.float(), b.cpu().float(), padding=1), what=f"conv 160-wide {H}x{W} {Cin}->{Cout} ups={ups}")
+    finally:
+        ops.plan_clear()
+        ops.set_kernel_variant(-1)
+        ops.set_halo_pipe_threshold(768)
+        ops.set_workspace(None)
+
+
 def test_conv_halo_matches_row_gather_igemm():
     """The two 3x3 implementations agree to fp32 summation-order noise on a plain conv (border + m-tail)."""
     B, H, W, Cin, Cout = 2, 20, 28, 192, 128
