@@ -17,7 +17,7 @@ import torch
 from . import ops
 
 
-def _candidates(key, meta, ws_bytes):
+def _candidates(key, meta, ws_bytes, cold=False):
     kind, M, N, K, aux = key
     nk = K // 64
     tiles = []
@@ -48,7 +48,10 @@ def _candidates(key, meta, ws_bytes):
             # the pipeline depth is NOT tuned here: replaying one launch keeps its weights cache-resident, which
             # hides exactly the latency the deeper variants exist for (in situ every weight byte comes from HBM);
             # the library's occupancy rule picks it (csrc/igemm.hip launch_cfg)
-            variants = (-1,)
+            # ... unless the timing itself runs cold (small-batch plans, see autotune(cold=True)): then the depth is a
+            # fair candidate for the GEMM kernels
+            # (GEMM: LDS ring depth 1/2/4; halo conv: 1 = single-buffer, 2 = pipelined weight ring)
+            variants = ((-1, 1, 2, 4) if kind == 0 else (1, 2) if meta["halo"] else (-1,)) if cold else (-1,)
             for v in variants:
                 out.append((bm, bn, s, v))
     return out
@@ -63,6 +66,36 @@ def _time(fn, reps):
     e1.record()
     e1.synchronize()
     return e0.elapsed_time(e1) / reps
+
+
+_FLUSH = {}
+
+
+def _time_cold(fn, reps):
+    """Per-launch time with every cache level flushed before each launch: at batch 1-2 a layer's weights always come
+    from HBM in situ (1.7 GB of UNet weights per step against 256 MB of MALL), while a back-to-back replay of one
+    layer keeps them cache-resident and favours the wrong tile / split-K / depth."""
+    dev = torch.cuda.current_device()
+    buf = _FLUSH.get(dev)
+    if buf is None:
+        buf = _FLUSH[dev] = torch.empty(768 << 20, dtype=torch.uint8, device="cuda")
+    fn()
+    total = 0.0
+    evs = []
+    for _ in range(reps):
+        buf.fill_(1)                              # 768 MB of writes: evicts L2 and MALL
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        evs.append((e0, e1))
+    evs[-1][1].synchronize()
+    ts = sorted(a.elapsed_time(b) for a, b in evs)
+    return sum(ts[:max(1, len(ts) // 2)]) / max(1, len(ts) // 2)      # mean of the faster half (event jitter is one-sided)
+
+
+def release_flush_buffers():
+    _FLUSH.clear()
 
 
 def _cache_path():
@@ -89,7 +122,7 @@ def _save_cache(cache):
             json.dump({",".join(str(v) for v in k): list(val) for k, val in cache.items()}, f)
 
 
-def autotune(records, ws_bytes, reps=None, verbose=False):
+def autotune(records, ws_bytes, reps=None, verbose=False, cold=False):
     """records: list of (key, meta, replay) from ops.RECORD.  Returns {key: (bm, bn, splits, variant, ms)}.
     LCM_TUNE_CACHE=<file> persists the winners (reproducible plans across processes, no tuning launches)."""
     reps = reps or int(os.environ.get("LCM_AUTOTUNE_REPS", "6"))
@@ -105,11 +138,14 @@ def autotune(records, ws_bytes, reps=None, verbose=False):
             chosen[key] = (bm, bn, s, v, float(cache[key][4]) if len(cache[key]) > 4 else 0.0)
             continue
         best = None
-        for (bm, bn, s, v) in _candidates(key, meta, ws_bytes):
+        for (bm, bn, s, v) in _candidates(key, meta, ws_bytes, cold):
             ops.plan_set(key[0], key[1], key[2], key[3], key[4], bm, bn, s, v)
-            # hold the stream briefly so the timed launches run back to back (host enqueue is slower than tiny kernels)
-            ops.debug_spin(150)
-            ms = _time(fn, reps)
+            if cold:
+                ms = _time_cold(fn, reps)
+            else:
+                # hold the stream briefly so the timed launches run back to back (host enqueue is slower than tiny kernels)
+                ops.debug_spin(150)
+                ms = _time(fn, reps)
             if best is None or ms < best[4]:
                 best = (bm, bn, s, v, ms)
         ops.plan_set(key[0], key[1], key[2], key[3], key[4], *best[:4])
@@ -121,4 +157,6 @@ def autotune(records, ws_bytes, reps=None, verbose=False):
                   f"splits {best[2]} variant {best[3]} {best[4] * 1e3:.1f}us")
     if dirty:
         _save_cache(cache)
+    if cold:
+        release_flush_buffers()
     return chosen

@@ -368,13 +368,13 @@ static int g_halo_pipe_below = 768;      // workgroup count under which the pipe
 extern "C" int lcm_set_halo_pipe_threshold(int wgs) { g_halo_pipe_below = wgs; return LCM_OK; }
 
 template <int TH, int TW, int BN, int XFORM, int PH>
-static void launch_halo(HaloParams& hp, hipStream_t s) {
+static void launch_halo(HaloParams& hp, hipStream_t s, int force) {     // force: 1 single-buffer, 2 pipelined, else by grid size
     constexpr int HROWS_PAD = ((TH + 2) * (TW + 2) + 7) / 8 * 8;
     hp.tiles_y = ((PH ? hp.g.Hin : hp.H) + TH - 1) / TH;
     hp.tiles_x = ((PH ? hp.g.Win : hp.W) + TW - 1) / TW;
     hp.g.ntiles = hp.g.N / BN;
     dim3 grid(hp.g.mtiles * hp.g.ntiles, hp.g.splits, 1);
-    if (!XFORM && (long long)grid.x * grid.y < g_halo_pipe_below) {
+    if (!XFORM && force != 1 && (force == 2 || (long long)grid.x * grid.y < g_halo_pipe_below)) {
         constexpr int WS = 3;
         constexpr int smem = 2 * HROWS_PAD * 128 + WS * BN * 128;
         static bool attr_set = false;
@@ -411,7 +411,7 @@ int lcm_conv_halo_launch(HaloParams& hp, int B, hipStream_t s, int* slabs_per_im
     const int nchunks = p.Cin >> 6;
     // candidates (BM, BN) by per-FLOP efficiency; split over channel chunks fills the chip for small images
     const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
-    int bm = 0, bn = 0, splits = 1;
+    int bm = 0, bn = 0, splits = 1, force = 0;
     long long best = -1;
     for (int c = 0; c < 4; ++c) {
         const int cbm = cand[c][0], cbn = cand[c][1];
@@ -439,6 +439,7 @@ int lcm_conv_halo_launch(HaloParams& hp, int B, hipStream_t s, int* slabs_per_im
             !(TW == 8 && pbm == 128)) {
             if (psp > 1 && (!p.ws || (long long)psp * p.M * p.N * 4 > ws_bytes || psp > nchunks)) psp = 1;
             bm = pbm; bn = pbn; splits = psp;
+            force = (pv == 1 || pv == 2) ? pv : 0;
         }
     }
     if (!bm) return 1;
@@ -459,9 +460,9 @@ int lcm_conv_halo_launch(HaloParams& hp, int B, hipStream_t s, int* slabs_per_im
     if (ph && xf) return 1;
 #define HALO_CASE(TH_, TW_, BN_)                                                           \
     if (th == TH_ && TW == TW_ && bn == BN_) {                                             \
-        if (ph) launch_halo<TH_, TW_, BN_, 0, 1>(hp, s);                                   \
-        else if (xf) launch_halo<TH_, TW_, BN_, 1, 0>(hp, s);                              \
-        else launch_halo<TH_, TW_, BN_, 0, 0>(hp, s);                                      \
+        if (ph) launch_halo<TH_, TW_, BN_, 0, 1>(hp, s, force);                            \
+        else if (xf) launch_halo<TH_, TW_, BN_, 1, 0>(hp, s, force);                       \
+        else launch_halo<TH_, TW_, BN_, 0, 0>(hp, s, force);                               \
     } else
     HALO_CASE(8, 16, 128) HALO_CASE(8, 16, 64) HALO_CASE(4, 16, 128) HALO_CASE(4, 16, 64)
     HALO_CASE(8, 8, 128) HALO_CASE(8, 8, 64) HALO_CASE(8, 16, 160) HALO_CASE(4, 16, 160) HALO_CASE(8, 8, 160) { return 1; }

@@ -179,7 +179,10 @@ class LcmHipPipeline:
                 recs, ops.RECORD = ops.RECORD, None
             self.stream.synchronize()
             todo = [r for r in recs if r[0] is not None and r[0] not in self._tuned_keys]
-            res = autotune.autotune(todo, self._splitk_ws.numel() * 4, verbose=verbose)
+            # small plans are weight-streaming bound: time their candidates with cold caches (autotune._time_cold)
+            cold_env = os.environ.get("LCM_AUTOTUNE_COLD", "auto")
+            cold = (P.B * P.h * P.w <= 2 * 64 * 64) if cold_env == "auto" else cold_env == "1"
+            res = autotune.autotune(todo, self._splitk_ws.numel() * 4, verbose=verbose, cold=cold)
             self._tuned_keys.update(res.keys())
             self.stream.synchronize()
         P.tuned = True
