@@ -146,7 +146,9 @@ int lcm_groupnorm_f16(const void* x, int C1, const void* x2, int C2, const void*
 
 /* GroupNorm (+SiLU) of [x | x2] from producer-written statistics (see lcm_gemm_f16): stats1 = [B*P1][C1][2],
  * stats2 = [B*P2][C2][2] (x2/stats2 NULL: single source).  ws: >= 8*B*(C1+C2) bytes.  No pass over the data for
- * the statistics: one finalize launch (per image x group) + the apply launch. */
+ * the statistics: one finalize launch (per image x group) + the apply launch.  out == NULL stops after the finalize
+ * and leaves the folded per-(image, channel) fp32 tables in ws (scale [B][C1+C2], then shift [B][C1+C2]) for
+ * lcm_conv3x3_gn_f16, which applies them while staging its input (x / x2 may then be NULL; C2 is taken as given). */
 int lcm_groupnorm_from_stats_f16(const void* x, int C1, const void* x2, int C2, const void* stats1, int P1,
                                  const void* stats2, int P2, const void* gamma, const void* beta, void* out,
                                  int B, int HW, int groups, float eps, int silu, void* ws, void* stream);

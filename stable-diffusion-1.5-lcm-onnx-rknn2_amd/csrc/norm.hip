@@ -288,8 +288,8 @@ static int launch_gn_apply(const void* x, int C1, const void* x2, int C2, const 
 extern "C" int lcm_groupnorm_from_stats_f16(const void* x, int C1, const void* x2, int C2, const void* stats1, int P1,
                                             const void* stats2, int P2, const void* gamma, const void* beta, void* out,
                                             int B, int HW, int groups, float eps, int silu, void* ws, void* stream) {
-    LCM_REQUIRE(x && stats1 && gamma && beta && out && ws, "groupnorm_from_stats: null pointer");
-    if (!x2) C2 = 0;
+    LCM_REQUIRE(stats1 && gamma && beta && ws && (x || !out), "groupnorm_from_stats: null pointer");
+    if (!x2 && !(out == nullptr && stats2)) C2 = 0;
     const int C = C1 + C2;
     LCM_REQUIRE(B > 0 && HW > 0 && groups > 0 && groups <= 64 && P1 > 0, "groupnorm_from_stats: bad shape");
     LCM_REQUIRE(C1 % 8 == 0 && C2 % 8 == 0 && C % groups == 0 && C <= GN_MAXC, "groupnorm_from_stats: bad channels %d+%d", C1, C2);
@@ -301,6 +301,7 @@ extern "C" int lcm_groupnorm_from_stats_f16(const void* x, int C1, const void* x
                        (const float*)stats2, P2, C2, (const half_t*)gamma, (const half_t*)beta, scale, shift, groups,
                        1.0f / ((float)HW * (float)(C / groups)), eps);
     LCM_CHECK_LAUNCH("gn_finalize_from_stats");
+    if (!out) return LCM_OK;        // tables only: ws = scale [B][C] | shift [B][C] for lcm_conv3x3_gn_f16
     return launch_gn_apply(x, C1, x2, C2, scale, shift, out, B, HW, silu, s);
 }
 

@@ -23,6 +23,20 @@ import os
 FUSED_GN_STATS = os.environ.get("LCM_FUSED_GN_STATS", "1") != "0"
 # Upsample2D (nearest-2x -> conv3x3) as four 2x2 phase convolutions on the low-resolution input (2.25x fewer MACs)
 UPS_PHASES = os.environ.get("LCM_UPS_PHASES", "1") != "0"
+# GroupNorm-apply(+SiLU) inside the consuming conv's halo staging instead of its own pass over HBM -- where it pays:
+# the staged element is transformed once per n-tile of the conv, so few n-tiles (<= 4 with the 160-wide tile, <= 3 with
+# 128) and a tensor too large for the Infinity Cache, so that the separate pass really is HBM time (in situ the apply pass
+# reads what the producer just wrote: below ~64 MB it is served from MALL and fusing gains nothing; measured +1.5 % at
+# batch 8 and +0.2 % at batch 1 with the VAE's 512^2 / 256^2 levels fused; tools/gn_fuse_bench.py has the cold numbers)
+FUSE_GN_CONV = os.environ.get("LCM_FUSE_GN_CONV", "1") != "0"
+FUSE_GN_MIN_BYTES = int(os.environ.get("LCM_FUSE_GN_MIN_BYTES", str(64 << 20)))
+
+
+def _fuse_gn_into_conv(M, Cin, Cout):
+    if not (FUSE_GN_CONV and FUSED_GN_STATS) or Cin % 64 or Cout % 64:
+        return False
+    ntiles = Cout // 160 if Cout % 160 == 0 else -(-Cout // 128)
+    return M * Cin * 2 >= FUSE_GN_MIN_BYTES and ntiles <= (4 if Cout % 160 == 0 else 3)
 
 
 class _Buffers:
@@ -104,13 +118,18 @@ class _Net:
         """-> (out, out_stats).  x_st / x2_st: fused statistics of the inputs (None: compute them standalone)."""
         HW, M, Cin = H * W, B * H * W, C1 + C2
         w = self.w
-        hn = self.buf.get("gn", M, Cin)
-        self.norm(x, w[p + ".norm1.g"], w[p + ".norm1.b"], hn, B, HW, C1, x_st=x_st, x2=x2, C2=C2, x2_st=x2_st, eps=eps)
+        have1 = x_st is not None and x_st.P > 0 and (x2 is None or (x2_st is not None and x2_st.P > 0))
         h1 = self.buf.get("conv1", M, Cout)
         h1_st = self.stats("conv1", M, Cout)
-        ops.conv3x3(hn, w[p + ".conv1.w"], h1, B, H, W, Cin, Cout, bias=w[p + ".conv1.b"], rowadd=rowadd, stats=h1_st)
-        hn2 = self.buf.get("gn", M, Cout)
-        self.norm(h1, w[p + ".norm2.g"], w[p + ".norm2.b"], hn2, B, HW, Cout, x_st=h1_st, eps=eps)
+        if have1 and C1 % 64 == 0 and C2 % 64 == 0 and _fuse_gn_into_conv(M, Cin, Cout):
+            sc_t, sh_t = ops.groupnorm_tables_from_stats(w[p + ".norm1.g"], w[p + ".norm1.b"], B, HW, C1, x_st, self.gn_ws(B, HW, Cin),
+                                                         C2=C2, st2=x2_st if x2 is not None else None, eps=eps)
+            ops.conv3x3_gn(x, w[p + ".conv1.w"], h1, B, H, W, C1, Cout, x2=x2, C2=C2, gn_scale=sc_t, gn_shift=sh_t, silu=True,
+                           bias=w[p + ".conv1.b"], rowadd=rowadd, stats=h1_st)
+        else:
+            hn = self.buf.get("gn", M, Cin)
+            self.norm(x, w[p + ".norm1.g"], w[p + ".norm1.b"], hn, B, HW, C1, x_st=x_st, x2=x2, C2=C2, x2_st=x2_st, eps=eps)
+            ops.conv3x3(hn, w[p + ".conv1.w"], h1, B, H, W, Cin, Cout, bias=w[p + ".conv1.b"], rowadd=rowadd, stats=h1_st)
         if (p + ".sc.w") in w:
             sc = self.buf.get("shortcut", M, Cout)
             ops.gemm(x, w[p + ".sc.w"], sc, bias=w[p + ".sc.b"], a2=x2)
@@ -118,7 +137,15 @@ class _Net:
             sc = x
         out = self.buf.get(out_role, M, Cout)
         out_st = self.stats(out_role, M, Cout)
-        ops.conv3x3(hn2, w[p + ".conv2.w"], out, B, H, W, Cout, Cout, bias=w[p + ".conv2.b"], res=sc, stats=out_st)
+        if h1_st.P > 0 and _fuse_gn_into_conv(M, Cout, Cout):
+            sc_t, sh_t = ops.groupnorm_tables_from_stats(w[p + ".norm2.g"], w[p + ".norm2.b"], B, HW, Cout, h1_st,
+                                                         self.gn_ws(B, HW, Cout), eps=eps)
+            ops.conv3x3_gn(h1, w[p + ".conv2.w"], out, B, H, W, Cout, Cout, gn_scale=sc_t, gn_shift=sh_t, silu=True,
+                           bias=w[p + ".conv2.b"], res=sc, stats=out_st)
+        else:
+            hn2 = self.buf.get("gn", M, Cout)
+            self.norm(h1, w[p + ".norm2.g"], w[p + ".norm2.b"], hn2, B, HW, Cout, x_st=h1_st, eps=eps)
+            ops.conv3x3(hn2, w[p + ".conv2.w"], out, B, H, W, Cout, Cout, bias=w[p + ".conv2.b"], res=sc, stats=out_st)
         return out, out_st
 
 

@@ -214,6 +214,17 @@ def groupnorm_from_stats(x, gamma, beta, out, B, HW, C1, st1, ws, *, x2=None, C2
     return out
 
 
+def groupnorm_tables_from_stats(gamma, beta, B, HW, C1, st1, ws, *, C2=0, st2=None, groups=32, eps=1e-5):
+    """Finalize only: -> (scale, shift) fp32 [B, C1+C2] views of ``ws`` for ``conv3x3_gn`` (the apply pass is skipped)."""
+    L = _lib.load()
+    C = C1 + (C2 if st2 is not None else 0)
+    rc = L.lcm_groupnorm_from_stats_f16(None, C1, None, C2 if st2 is not None else 0, _p(st1.buf), st1.P,
+                                        _p(st2.buf) if st2 is not None else None, st2.P if st2 is not None else 0,
+                                        _p(gamma), _p(beta), None, B, HW, groups, float(eps), 0, _p(ws), _stream())
+    _lib.check(rc, "lcm_groupnorm_from_stats_f16")
+    return ws[:B * C].view(B, C), ws[B * C:2 * B * C].view(B, C)
+
+
 def layernorm(x, gamma, beta, out, M, C, eps=1e-5):
     L = _lib.load()
     _lib.check(L.lcm_layernorm_f16(_p(x), _p(gamma), _p(beta), _p(out), M, C, float(eps), _stream()), "lcm_layernorm_f16")
