@@ -102,16 +102,29 @@ def _cache_path():
     return os.environ.get("LCM_TUNE_CACHE", "")
 
 
-def _load_cache():
+PACKAGED_PLANS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_plans_gfx950.json")
+
+
+def _read_plans(p):
     import json
+    try:
+        with open(p) as f:
+            return {tuple(int(v) for v in k.split(",")): tuple(val) for k, val in json.load(f).items()}
+    except Exception:
+        return {}
+
+
+def _load_cache():
+    """Plans known before any tuning launch: the table shipped with the package (tools/make_plans.py: the standard
+    SD1.5 / SDXL request shapes, tuned on an MI355X with many cold repetitions -- launch parameters only, results are
+    unaffected) overlaid by the user's LCM_TUNE_CACHE file.  LCM_TUNED_PLANS=0 ignores the shipped table."""
+    cache = {}
+    if os.environ.get("LCM_TUNED_PLANS", "1") != "0" and os.path.exists(PACKAGED_PLANS):
+        cache.update(_read_plans(PACKAGED_PLANS))
     p = _cache_path()
     if p and os.path.exists(p):
-        try:
-            with open(p) as f:
-                return {tuple(int(v) for v in k.split(",")): tuple(val) for k, val in json.load(f).items()}
-        except Exception:
-            return {}
-    return {}
+        cache.update(_read_plans(p))
+    return cache
 
 
 def _save_cache(cache):
