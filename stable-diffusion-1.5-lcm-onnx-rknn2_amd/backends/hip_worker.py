@@ -144,13 +144,13 @@ class HipLcmWorker:
             if os.path.isdir(ckpt) and os.path.exists(os.path.join(ckpt, "model_index.json")):
                 usd, ucfg, vsd, vcfg = _weights.load_diffusers_dir(ckpt)          # cuda_worker.py:66-77
                 format_name = "diffusers"
-            elif os.path.isfile(ckpt) and ckpt.endswith(".safetensors") and self.FAMILY == "sd15":
-                usd, ucfg, vsd, vcfg, clip_sd = _weights.load_single_file(ckpt)   # cuda_worker.py:78-85
+            elif os.path.isfile(ckpt) and ckpt.endswith(".safetensors"):
+                loader = _weights.load_single_file if self.FAMILY == "sd15" else _weights.load_single_file_sdxl
+                usd, ucfg, vsd, vcfg, clip_sd = loader(ckpt)                       # cuda_worker.py:78-85 / :330-352
                 format_name = "single-file"
             else:
-                raise RuntimeError(f"{ckpt}: expected a diffusers directory (model_index.json)"
-                                   + (" or a .safetensors file" if self.FAMILY == "sd15" else "")
-                                   + " (.ckpt pickles are not loaded: they execute code)")
+                raise RuntimeError(f"{ckpt}: expected a diffusers directory (model_index.json) or a .safetensors file"
+                                   " (.ckpt pickles are not loaded: they execute code)")
             cad = int(ucfg.get("cross_attention_dim", 768))
             if (cad in (2048, 1280)) != (self.FAMILY == "sdxl"):
                 raise RuntimeError(f"Loaded UNet with cross_attention_dim={cad} into the {self.FAMILY} worker "
@@ -348,9 +348,18 @@ class HipLcmSDXLWorker(HipLcmWorker):
         from ..clip import CLIP_BIGG, CLIP_L, ClipTextHip, HashTokenizer, load_clip_dir, synthetic_clip
         from ..prompt import _BpeTokenizer
         self._enc, self._tok = [], []
-        for sub, tsub, cfg0, seed in (("text_encoder", "tokenizer", CLIP_L, 2), ("text_encoder_2", "tokenizer_2", CLIP_BIGG, 3)):
+        for idx, (sub, tsub, cfg0, seed) in enumerate((("text_encoder", "tokenizer", CLIP_L, 2),
+                                                       ("text_encoder_2", "tokenizer_2", CLIP_BIGG, 3))):
             d = os.path.join(ckpt_root, sub) if ckpt_root else None
-            if d and os.path.isdir(d):
+            if clip_sd is not None and clip_sd[idx] is not None:          # carried inside a single-file checkpoint
+                sd = clip_sd[idx]
+                D = sd["embeddings.token_embedding.weight"].shape[1]
+                cfg = dict(cfg0, hidden_size=D, vocab_size=sd["embeddings.token_embedding.weight"].shape[0],
+                           num_hidden_layers=1 + max(int(k.split(".")[2]) for k in sd if k.startswith("encoder.layers.")),
+                           intermediate_size=sd["encoder.layers.0.mlp.fc1.weight"].shape[0], num_attention_heads=D // 64)
+                if "text_projection.weight" in sd:
+                    cfg["projection_dim"] = sd["text_projection.weight"].shape[0]
+            elif d and os.path.isdir(d):
                 sd, cfg = load_clip_dir(d)
                 cfg = dict(cfg0, **cfg)
             else:

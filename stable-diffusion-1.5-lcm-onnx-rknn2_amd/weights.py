@@ -268,6 +268,8 @@ def _ldm_unet_key(k: str, layers_per_block: int = 2, down_attn=(True, True, True
     per = layers_per_block + 1
     if p[0] == "time_embed":
         return {"0": "time_embedding.linear_1", "2": "time_embedding.linear_2"}[p[1]] + "." + p[2]
+    if p[0] == "label_emb":                                                   # SDXL text_time additional embedding
+        return {"0": "add_embedding.linear_1", "2": "add_embedding.linear_2"}[p[2]] + "." + p[3]
     if p[0] == "input_blocks":
         i = int(p[1])
         if i == 0:
@@ -365,3 +367,88 @@ def load_single_file(path: str):
         if tuple(vsd[name].shape) != tuple(shape):
             vsd[name] = vsd[name].reshape(shape)
     return usd, ucfg, vsd, vcfg, (csd or None)
+
+
+def _openclip_text_key(k: str):
+    """'conditioner.embedders.1.model.' key (prefix stripped; OpenCLIP text tower as SDXL single files carry it) ->
+    list of (transformers CLIPTextModelWithProjection key without 'text_model.', transform) pairs."""
+    if k == "token_embedding.weight":
+        return [("embeddings.token_embedding.weight", None)]
+    if k == "positional_embedding":
+        return [("embeddings.position_embedding.weight", None)]
+    if k.startswith("ln_final."):
+        return [("final_layer_norm." + k.split(".")[1], None)]
+    if k == "text_projection":
+        return [("text_projection.weight", "T")]                              # x @ P  ->  Linear weight P^T
+    if k.startswith("transformer.resblocks."):
+        p = k.split(".")
+        base = f"encoder.layers.{p[2]}."
+        rest = ".".join(p[3:])
+        simple = {"ln_1": "layer_norm1", "ln_2": "layer_norm2", "mlp.c_fc": "mlp.fc1", "mlp.c_proj": "mlp.fc2",
+                  "attn.out_proj": "self_attn.out_proj"}
+        for old, new in simple.items():
+            if rest.startswith(old + "."):
+                return [(base + new + rest[len(old):], None)]
+        if rest in ("attn.in_proj_weight", "attn.in_proj_bias"):
+            kind = rest.rsplit("_", 1)[1]
+            return [(base + f"self_attn.{n}_proj.{kind}", ("chunk", i)) for i, n in enumerate("qkv")]
+    return []                                                                  # logit_scale, attn_mask ...
+
+
+def load_single_file_sdxl(path: str):
+    """Original-layout SDXL .safetensors -> (unet_sd, unet_cfg, vae_sd, vae_cfg, [clip_l_sd, clip_bigg_sd]).
+    UNet: model.diffusion_model.* (3 levels, label_emb = text_time embedding); VAE: first_stage_model.*; text encoders:
+    conditioner.embedders.0.transformer.text_model.* (CLIP-L, transformers names) and conditioner.embedders.1.model.*
+    (OpenCLIP bigG: fused in_proj split into q/k/v, text_projection transposed).  The reference reaches this through
+    StableDiffusionXLPipeline.from_single_file (backends/cuda_worker.py:330-352)."""
+    from safetensors.torch import load_file
+    from .config import SDXL_UNET
+    raw = load_file(path)
+    if not any(k.startswith("model.diffusion_model.label_emb.") for k in raw):
+        raise RuntimeError(f"{path}: not an original-layout SDXL checkpoint (no model.diffusion_model.label_emb.*)")
+    usd, vsd, c1, c2 = {}, {}, {}, {}
+    down_attn = SDXL_UNET["down_attn"]
+    for k, v in raw.items():
+        if k.startswith("model.diffusion_model."):
+            nk = _ldm_unet_key(k[len("model.diffusion_model."):], 2, down_attn)
+            if nk:
+                usd[nk] = v.to(torch.float16)
+        elif k.startswith("first_stage_model."):
+            nk = _ldm_vae_key(k[len("first_stage_model."):])
+            if nk:
+                vsd[nk] = v.to(torch.float16)
+        elif k.startswith("conditioner.embedders.0.transformer."):
+            kk = k[len("conditioner.embedders.0.transformer."):]
+            kk = kk[len("text_model."):] if kk.startswith("text_model.") else kk
+            if "position_ids" not in kk:
+                c1[kk] = v.to(torch.float16)
+        elif k.startswith("conditioner.embedders.1.model."):
+            for nk, tf in _openclip_text_key(k[len("conditioner.embedders.1.model."):]):
+                t = v
+                if tf == "T":
+                    t = v.t()
+                elif tf is not None:
+                    t = v.chunk(3, dim=0)[tf[1]]
+                c2[nk] = t.to(torch.float16).contiguous()
+    if "conv_in.weight" not in usd or "add_embedding.linear_1.weight" not in usd:
+        raise RuntimeError(f"{path}: not an original-layout SDXL checkpoint (no model.diffusion_model.label_emb.*)")
+    boc = (usd["conv_in.weight"].shape[0], usd["down_blocks.1.resnets.0.conv1.weight"].shape[0],
+           usd["down_blocks.2.resnets.0.conv1.weight"].shape[0])
+    depth = tuple(0 if not down_attn[b] else
+                  1 + max(int(k.split(".")[5]) for k in usd if k.startswith(f"down_blocks.{b}.attentions.0.transformer_blocks."))
+                  for b in range(3))
+    cad = usd["down_blocks.1.attentions.0.transformer_blocks.0.attn2.to_k.weight"].shape[1]
+    ucfg = unet_config(dict(SDXL_UNET, block_out_channels=boc, cross_attention_dim=cad,
+                            transformer_layers_per_block=tuple(max(1, d) for d in depth),
+                            attention_head_dim=tuple(c // 64 for c in boc),
+                            projection_class_embeddings_input_dim=usd["add_embedding.linear_1.weight"].shape[1]))
+    vboc = (vsd["decoder.up_blocks.3.resnets.0.conv1.weight"].shape[0], vsd["decoder.up_blocks.2.resnets.0.conv1.weight"].shape[0],
+            vsd["decoder.up_blocks.1.resnets.0.conv1.weight"].shape[0], vsd["decoder.conv_in.weight"].shape[0])
+    vcfg = vae_config(dict(block_out_channels=vboc, scaling_factor=0.13025, sample_size=1024))
+    for what, sd, spec in (("unet", usd, unet_param_spec(ucfg)), ("vae", vsd, vae_param_spec(vcfg))):
+        for name, shape, _ in spec:
+            if name not in sd:
+                raise RuntimeError(f"checkpoint/graph mismatch at {what} '{name}': missing")
+            if tuple(sd[name].shape) != tuple(shape):
+                sd[name] = sd[name].reshape(shape)
+    return usd, ucfg, vsd, vcfg, [c1 or None, c2 or None]

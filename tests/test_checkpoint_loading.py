@@ -130,7 +130,7 @@ def test_worker_runs_from_checkpoint_directory(tmp_path, monkeypatch):
         w.close()
 
 
-def _to_ldm_names(usd, vsd, csd):
+def _to_ldm_names(usd, vsd, csd, up_attn=(False, True, True, True)):
     """Independent inverse of the loader's mapping: diffusers names -> original (LDM) single-file names."""
     out = {}
     res = {"norm1": "in_layers.0", "conv1": "in_layers.2", "time_emb_proj": "emb_layers.1", "norm2": "out_layers.0",
@@ -146,6 +146,8 @@ def _to_ldm_names(usd, vsd, csd):
             n = "input_blocks.0.0." + p[1]
         elif p[0] == "time_embedding":
             n = "time_embed.cond_proj.weight" if p[1] == "cond_proj" else f"time_embed.{0 if p[1] == 'linear_1' else 2}.{p[2]}"
+        elif p[0] == "add_embedding":
+            n = f"label_emb.0.{0 if p[1] == 'linear_1' else 2}.{p[2]}"
         elif p[0] == "down_blocks":
             b = int(p[1])
             if p[2] == "downsamplers":
@@ -158,7 +160,7 @@ def _to_ldm_names(usd, vsd, csd):
         elif p[0] == "up_blocks":
             b = int(p[1])
             if p[2] == "upsamplers":
-                n = f"output_blocks.{3 * b + 2}.{1 if b == 0 else 2}.conv.{p[-1]}"
+                n = f"output_blocks.{3 * b + 2}.{2 if up_attn[b] else 1}.conv.{p[-1]}"
             else:
                 i = 3 * b + int(p[3])
                 n = f"output_blocks.{i}.0." + r(".".join(p[4:])) if p[2] == "resnets" else f"output_blocks.{i}.1." + ".".join(p[4:])
@@ -188,11 +190,128 @@ def _to_ldm_names(usd, vsd, csd):
             else:
                 n = f"decoder.up.{3 - int(p[1])}.upsample.conv.{p[-1]}"
         out["first_stage_model." + n] = v
-    for k, v in csd.items():
+    for k, v in (csd or {}).items():
         out["cond_stage_model.transformer.text_model." + k] = v
-    out["cond_stage_model.transformer.text_model.embeddings.position_ids"] = torch.arange(77).unsqueeze(0)
+    if csd:
+        out["cond_stage_model.transformer.text_model.embeddings.position_ids"] = torch.arange(77).unsqueeze(0)
     out["first_stage_model.encoder.conv_in.weight"] = torch.zeros(4, 3, 3, 3, dtype=torch.float16)
     return out
+
+
+def _to_openclip_names(sd):
+    """transformers CLIPTextModelWithProjection names -> the OpenCLIP text-tower names SDXL single files use."""
+    out, L = {}, 1 + max(int(k.split(".")[2]) for k in sd if k.startswith("encoder.layers."))
+    out["token_embedding.weight"] = sd["embeddings.token_embedding.weight"]
+    out["positional_embedding"] = sd["embeddings.position_embedding.weight"]
+    for t in ("weight", "bias"):
+        out[f"ln_final.{t}"] = sd[f"final_layer_norm.{t}"]
+    out["text_projection"] = sd["text_projection.weight"].t().contiguous()
+    out["logit_scale"] = torch.tensor(4.6)
+    for i in range(L):
+        a, b = f"encoder.layers.{i}.", f"transformer.resblocks.{i}."
+        for t in ("weight", "bias"):
+            out[b + f"ln_1.{t}"], out[b + f"ln_2.{t}"] = sd[a + f"layer_norm1.{t}"], sd[a + f"layer_norm2.{t}"]
+            out[b + f"mlp.c_fc.{t}"], out[b + f"mlp.c_proj.{t}"] = sd[a + f"mlp.fc1.{t}"], sd[a + f"mlp.fc2.{t}"]
+            out[b + f"attn.out_proj.{t}"] = sd[a + f"self_attn.out_proj.{t}"]
+            out[b + f"attn.in_proj_{t}"] = torch.cat([sd[a + f"self_attn.{n}_proj.{t}"] for n in "qkv"], dim=0)
+    return out
+
+
+def test_sdxl_single_file_checkpoint_round_trip(tmp_path, monkeypatch):
+    """Original-layout SDXL .safetensors: 3-level UNet with label_emb, CLIP-L in transformers names under
+    conditioner.embedders.0, OpenCLIP bigG names under conditioner.embedders.1 (fused in_proj, transposed projection)."""
+    from safetensors.torch import save_file
+    from sdlcm_amd import weights
+    from sdlcm_amd.clip import clip_param_spec, synthetic_clip
+    from sdlcm_amd.config import SDXL_UNET, unet_config
+    from sdlcm_amd.backends import worker_factory
+    ucfg = unet_config(dict(SDXL_UNET, block_out_channels=(64, 128, 192), attention_head_dim=(1, 2, 3), cross_attention_dim=1280,
+                            transformer_layers_per_block=(1, 2, 3), projection_class_embeddings_input_dim=256 + 6 * 256))
+    usd = weights.synthetic_state_dict(weights.unet_param_spec(ucfg), 0)
+    vsd = weights.synthetic_state_dict(weights.vae_param_spec(VCFG), 1)
+    c1 = synthetic_clip(dict(num_hidden_layers=1, hidden_size=512, intermediate_size=1024, num_attention_heads=8, vocab_size=1000))
+    c2 = synthetic_clip(dict(num_hidden_layers=2, hidden_size=768, intermediate_size=1536, num_attention_heads=12, vocab_size=1000,
+                             hidden_act="gelu", projection_dim=256), seed=3)
+    assert "text_projection.weight" in c2
+    raw = _to_ldm_names(usd, vsd, None, up_attn=(True, True, False))
+    for k, v in c1.items():
+        raw["conditioner.embedders.0.transformer.text_model." + k] = v
+    for k, v in _to_openclip_names(c2).items():
+        raw["conditioner.embedders.1.model." + k] = v
+    path = str(tmp_path / "sdxl.safetensors")
+    save_file({k: v.contiguous() for k, v in raw.items()}, path)
+    lu, lucfg, lv, lvcfg, (l1, l2) = weights.load_single_file_sdxl(path)
+    assert lucfg["block_out_channels"] == (64, 128, 192) and lucfg["cross_attention_dim"] == 1280
+    assert tuple(lucfg["transformer_layers_per_block"]) == (1, 2, 3) and lucfg["projection_class_embeddings_input_dim"] == 1792
+    assert lvcfg["scaling_factor"] == 0.13025 and lvcfg["sample_size"] == 1024
+    for got, ref in ((lu, usd), (lv, vsd), (l1, c1), (l2, c2)):
+        assert set(got) == set(ref), set(got) ^ set(ref)
+        assert all(torch.equal(got[k], ref[k]) for k in ref)
+    monkeypatch.setenv("MODEL_ROOT", str(tmp_path))
+    monkeypatch.setenv("MODEL", "sdxl.safetensors")
+    assert worker_factory.detect_worker_type() == "sdxl"
+    with pytest.raises(RuntimeError):
+        weights.load_single_file_sdxl(str(tmp_path / "model_sd15_missing.safetensors")) if False else weights.load_single_file_sdxl(_sd15_file(tmp_path))
+
+
+@pytest.mark.gpu
+def test_sdxl_worker_runs_from_single_file(tmp_path, monkeypatch):
+    """A narrow synthetic SDXL single-file checkpoint (LDM UNet names, CLIP-L + OpenCLIP text towers inside) drives
+    HipLcmSDXLWorker end to end, with and without classifier-free guidance."""
+    from dataclasses import dataclass
+    from safetensors.torch import save_file
+    from sdlcm_amd import weights
+    from sdlcm_amd.clip import synthetic_clip
+    from sdlcm_amd.config import SDXL_UNET, unet_config
+    from sdlcm_amd.backends import worker_factory
+
+    @dataclass
+    class Req:
+        prompt: str = "a lighthouse"
+        size: str = "128x128"
+        num_inference_steps: int = 2
+        guidance_scale: float = 1.0
+        seed: int = 3
+
+    @dataclass
+    class J:
+        req: Req
+
+    ucfg = unet_config(dict(SDXL_UNET, block_out_channels=(64, 128, 192), attention_head_dim=(1, 2, 3), cross_attention_dim=1280,
+                            transformer_layers_per_block=(1, 2, 3), projection_class_embeddings_input_dim=256 + 6 * 256))
+    usd = weights.synthetic_state_dict(weights.unet_param_spec(ucfg), 0)
+    vsd = weights.synthetic_state_dict(weights.vae_param_spec(dict(VCFG, block_out_channels=(64, 128, 128, 128))), 1)
+    c1 = synthetic_clip(dict(num_hidden_layers=1, hidden_size=512, intermediate_size=1024, num_attention_heads=8, vocab_size=1000))
+    c2 = synthetic_clip(dict(num_hidden_layers=2, hidden_size=768, intermediate_size=1536, num_attention_heads=12, vocab_size=1000,
+                             hidden_act="gelu", projection_dim=256), seed=3)
+    raw = _to_ldm_names(usd, vsd, None, up_attn=(True, True, False))
+    raw.update({"conditioner.embedders.0.transformer.text_model." + k: v for k, v in c1.items()})
+    raw.update({"conditioner.embedders.1.model." + k: v for k, v in _to_openclip_names(c2).items()})
+    save_file({k: v.contiguous() for k, v in raw.items()}, str(tmp_path / "sdxl.safetensors"))
+    monkeypatch.setenv("MODEL_ROOT", str(tmp_path))
+    monkeypatch.setenv("MODEL", "sdxl.safetensors")
+    monkeypatch.delenv("LCM_HIP_SYNTHETIC", raising=False)
+    w = worker_factory.create_hip_worker(worker_id=5)
+    try:
+        assert type(w).__name__ == "HipLcmSDXLWorker"
+        png, seed = w.run_job(J(Req()))
+        assert seed == 3 and png[:8] == b"\x89PNG\r\n\x1a\n"
+        png2, _ = w.run_job(J(Req()))
+        assert png2 == png
+        png3, _ = w.run_job(J(Req(guidance_scale=5.0)))
+        assert png3[:8] == b"\x89PNG\r\n\x1a\n" and png3 != png
+    finally:
+        w.close()
+
+
+def _sd15_file(tmp_path):
+    from safetensors.torch import save_file
+    from sdlcm_amd import weights
+    usd = weights.synthetic_state_dict(weights.unet_param_spec(dict(UCFG, block_out_channels=(64, 128, 192, 192))), 0)
+    vsd = weights.synthetic_state_dict(weights.vae_param_spec(VCFG), 1)
+    p = str(tmp_path / "sd15.safetensors")
+    save_file({k: v.contiguous() for k, v in _to_ldm_names(usd, vsd, None).items()}, p)
+    return p
 
 
 def test_single_file_checkpoint_round_trip(tmp_path, monkeypatch):
