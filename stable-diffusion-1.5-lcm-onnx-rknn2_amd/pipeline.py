@@ -197,8 +197,10 @@ class LcmHipPipeline:
     # ------------------------------------------------------------------------------------------
     @torch.inference_mode()
     def generate(self, prompt_embeds, seeds, width, height, steps, guidance_scale=1.0, negative_embeds=None,
-                 want_float=False, taps=None, latents=None, added=None, negative_added=None):
-        """prompt_embeds: [B,77,ctx] (any float dtype, host or device); seeds: B ints.
+                 want_float=False, taps=None, latents=None, added=None, negative_added=None, noises=None):
+        """prompt_embeds: [B,77,ctx] (any float dtype, host or device); seeds: B ints.  noises: optional per-request
+        ``draw_noise(seed, h, w, steps - 1, init_noise_sigma)`` results drawn ahead by the callers (the worker's pool
+        threads draw them in parallel, off the dispatcher's serial path); None: drawn here from the seeds.
         Returns dict(rgb uint8 [B,H,W,3] (host), latents fp32 [B,4,h,w] (host), pool8 fp16 [B,4,8,8] (host))."""
         torch.cuda.set_device(self.device)        # the pool may call from a thread other than the constructing one
         pe = torch.as_tensor(prompt_embeds)
@@ -221,7 +223,7 @@ class LcmHipPipeline:
                     P.h_lat[b].copy_(torch.as_tensor(latents[b]).reshape(4, h, w))
                     extra = []
                 else:
-                    l0, extra = draw_noise(s, h, w, steps - 1, self.sched.init_noise_sigma)
+                    l0, extra = noises[b] if noises is not None else draw_noise(s, h, w, steps - 1, self.sched.init_noise_sigma)
                     P.h_lat[b].copy_(l0[0])
                 for i, n in enumerate(extra):
                     P.h_noise[i, b].copy_(n[0])

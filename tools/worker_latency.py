@@ -4,6 +4,7 @@ import os, sys, time, statistics
 from dataclasses import dataclass
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["MODEL"] = "synthetic"
+os.environ["LCM_WORKER_TIMING"] = "1"
 import sdlcm_amd  # noqa
 from sdlcm_amd.backends.worker_factory import create_hip_worker
 from sdlcm_amd.backends import hip_worker
@@ -62,6 +63,13 @@ for nthreads in (1, 2, 4, 8, 16):
     bs = w._engine.batcher.batches[n0:] if w._engine.batcher else []
     print(f"{nthreads:2d} callers: {nthreads * per / dt:6.1f} img/s  run_job p50 {allp[len(allp) // 2]:.1f} ms p95 {allp[int(len(allp) * 0.95)]:.1f} ms  "
           f"passes {len(bs)} mean batch {sum(bs) / max(1, len(bs)):.2f}", flush=True)
+    tm = w._engine.timing
+    if tm:
+        big = [x for x in tm[-len(bs):] if x[0] == max(b for b in bs)] if bs else []
+        if len(big) > 2:
+            gaps = [b[3] - a[3] - b[1] - b[2] for a, b in zip(big, big[1:])]
+            print(f"    batches of {big[0][0]}: conditioning {1e3 * sum(x[1] for x in big) / len(big):.1f} ms, sampler call {1e3 * sum(x[2] for x in big) / len(big):.1f} ms, "
+                  f"dispatcher idle between passes {1e3 * sum(gaps) / len(gaps):.1f} ms", flush=True)
     for x in ws[1:]:
         x.close()
 w.close()
