@@ -149,6 +149,9 @@ int lcm_groupnorm_f16(const void* x, int C1, const void* x2, int C2, const void*
  * the statistics: one finalize launch (per image x group) + the apply launch.  out == NULL stops after the finalize
  * and leaves the folded per-(image, channel) fp32 tables in ws (scale [B][C1+C2], then shift [B][C1+C2]) for
  * lcm_conv3x3_gn_f16, which applies them while staging its input (x / x2 may then be NULL; C2 is taken as given). */
+/* Tensors of at most this many bytes (default 8 MiB) run lcm_groupnorm_from_stats_f16 as ONE launch (each workgroup
+ * re-derives its group's statistics, then applies its pixel slice): small-batch passes are launch-latency bound. */
+int lcm_set_gn_fused_bytes(int64_t bytes);
 int lcm_groupnorm_from_stats_f16(const void* x, int C1, const void* x2, int C2, const void* stats1, int P1,
                                  const void* stats2, int P2, const void* gamma, const void* beta, void* out,
                                  int B, int HW, int groups, float eps, int silu, void* ws, void* stream);

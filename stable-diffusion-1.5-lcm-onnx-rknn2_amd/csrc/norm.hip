@@ -217,6 +217,79 @@ __global__ __launch_bounds__(256) void gn_finalize_from_stats_kernel(const float
     }
 }
 
+// One launch for SMALL tensors (batch 1-2 UNet levels, the VAE's 64^2 level), where finalize + apply are two launches
+// at the ~3 us launch floor each: workgroup (pixel slice, image, group) re-derives its group's mean / rstd from the
+// producer statistics -- P * cpg * 8 bytes out of L2, cheap to repeat per slice -- and applies the affine (+SiLU) to its
+// slice of pixels for the group's cpg channels.  Same arithmetic as the two-launch path.
+typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void gn_from_stats_fused_kernel(const half_t* __restrict__ x, int C1, const half_t* __restrict__ x2, int C2,
+                                                                  const float* __restrict__ st1, int P1, const float* __restrict__ st2, int P2,
+                                                                  const half_t* __restrict__ gamma, const half_t* __restrict__ beta,
+                                                                  half_t* __restrict__ out, int HW, int groups, float inv_count, float eps,
+                                                                  int silu, int rows_per_wg) {
+    __shared__ float rs[256], rq[256];
+    __shared__ float sc_s[128], sh_s[128];
+    const int C = C1 + C2, cpg = C / groups;
+    const int bg = blockIdx.y, b = bg / groups, g = bg - b * groups, tid = threadIdx.x;
+    const int c_lo = g * cpg, c_hi = c_lo + cpg;
+    float s = 0.f, q = 0.f;
+    auto accumulate = [&](const float* __restrict__ st, int P, int Cs, int a, int w) {
+        if (w <= 0 || st == nullptr) return;
+        const int spl = 256 / w;
+        const int sl = tid / w, jc = tid - sl * w;
+        if (sl >= spl) return;
+        const float* base = st + ((long long)b * P * Cs + a + jc) * 2;
+        const long long stride = (long long)Cs * 2;
+        int pp = sl;
+        for (; pp + 3 * spl < P; pp += 4 * spl) {
+            const float2 v0 = *reinterpret_cast<const float2*>(base + pp * stride);
+            const float2 v1 = *reinterpret_cast<const float2*>(base + (pp + spl) * stride);
+            const float2 v2 = *reinterpret_cast<const float2*>(base + (pp + 2 * spl) * stride);
+            const float2 v3 = *reinterpret_cast<const float2*>(base + (pp + 3 * spl) * stride);
+            s += (v0.x + v1.x) + (v2.x + v3.x);
+            q += (v0.y + v1.y) + (v2.y + v3.y);
+        }
+        for (; pp < P; pp += spl) {
+            const float2 v = *reinterpret_cast<const float2*>(base + pp * stride);
+            s += v.x; q += v.y;
+        }
+    };
+    accumulate(st1, P1, C1, c_lo, min(c_hi, C1) - c_lo);
+    accumulate(st2, P2, C2, max(c_lo, C1) - C1, c_hi - max(c_lo, C1));
+    rs[tid] = s; rq[tid] = q;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) { rs[tid] += rs[tid + o]; rq[tid] += rq[tid + o]; }
+        __syncthreads();
+    }
+    const float mean = rs[0] * inv_count;
+    const float rstd = rsqrtf(fmaxf(rq[0] * inv_count - mean * mean, 0.f) + eps);
+    if (tid < cpg) {
+        const float a = rstd * (float)gamma[c_lo + tid];
+        sc_s[tid] = a;
+        sh_s[tid] = (float)beta[c_lo + tid] - mean * a;
+    }
+    __syncthreads();
+    // apply: work item = (pixel, channel pair of the group); consecutive threads take consecutive pairs of one pixel
+    const int hp = cpg >> 1;
+    const int r0 = blockIdx.x * rows_per_wg, r1 = min(HW, r0 + rows_per_wg);
+    const long long rowbase = (long long)b * HW;
+    const int items = (r1 - r0) * hp;
+    for (int i = tid; i < items; i += 256) {
+        const int pr = i / hp, j = i - pr * hp;
+        const int c = c_lo + 2 * j;
+        const long long row = rowbase + r0 + pr;
+        const h2v v = (c < C1) ? *reinterpret_cast<const h2v*>(x + row * C1 + c) : *reinterpret_cast<const h2v*>(x2 + row * C2 + (c - C1));
+        float f0 = (float)v[0] * sc_s[2 * j] + sh_s[2 * j], f1 = (float)v[1] * sc_s[2 * j + 1] + sh_s[2 * j + 1];
+        if (silu) { f0 = silu_f(f0); f1 = silu_f(f1); }
+        h2v o = {(half_t)f0, (half_t)f1};
+        *reinterpret_cast<h2v*>(out + row * C + c) = o;
+    }
+}
+
+static long long g_gn_fused_bytes = 8ll << 20;   // tensors up to this size take the single-launch path above
+extern "C" int lcm_set_gn_fused_bytes(int64_t bytes) { g_gn_fused_bytes = bytes; return LCM_OK; }
+
 static inline int gn_rows(int B, int HW) {
     long long r = ((long long)B * HW + 1023) / 1024;
     if (r < 16) r = 16;
@@ -295,6 +368,19 @@ extern "C" int lcm_groupnorm_from_stats_f16(const void* x, int C1, const void* x
     LCM_REQUIRE(C1 % 8 == 0 && C2 % 8 == 0 && C % groups == 0 && C <= GN_MAXC, "groupnorm_from_stats: bad channels %d+%d", C1, C2);
     LCM_REQUIRE(C2 == 0 || (stats2 && P2 > 0), "groupnorm_from_stats: second source needs its statistics");
     hipStream_t s = (hipStream_t)stream;
+    const int cpg = C / groups;
+    if (out && (long long)B * HW * C * 2 <= g_gn_fused_bytes && cpg % 2 == 0 && cpg <= 128) {
+        int nslice = 512 / (B * groups);
+        if (nslice < 1) nslice = 1;
+        if (nslice > (HW + 31) / 32) nslice = (HW + 31) / 32;
+        const int rows = (HW + nslice - 1) / nslice;
+        hipLaunchKernelGGL(gn_from_stats_fused_kernel, dim3((HW + rows - 1) / rows, B * groups), dim3(256), 0, s,
+                           (const half_t*)x, C1, (const half_t*)x2, C2, (const float*)stats1, P1, (const float*)stats2, P2,
+                           (const half_t*)gamma, (const half_t*)beta, (half_t*)out, HW, groups,
+                           1.0f / ((float)HW * (float)cpg), eps, silu, rows);
+        LCM_CHECK_LAUNCH("gn_from_stats_fused");
+        return LCM_OK;
+    }
     float* scale = (float*)ws;
     float* shift = scale + (long long)B * C;
     hipLaunchKernelGGL(gn_finalize_from_stats_kernel, dim3(B * groups), dim3(256), 0, s, (const float*)stats1, P1, C1,

@@ -303,6 +303,10 @@ def set_tuning(target_wgs=0, max_splits=0, min_wgs=0):
     _lib.check(_lib.load().lcm_set_tuning(int(target_wgs), int(max_splits), int(min_wgs)), "lcm_set_tuning")
 
 
+def set_gn_fused_bytes(n):
+    _lib.check(_lib.load().lcm_set_gn_fused_bytes(int(n)), "lcm_set_gn_fused_bytes")
+
+
 def set_kernel_variant(v):
     _lib.check(_lib.load().lcm_set_kernel_variant(int(v)), "lcm_set_kernel_variant")
 

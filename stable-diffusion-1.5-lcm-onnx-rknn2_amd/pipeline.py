@@ -120,6 +120,8 @@ class LcmHipPipeline:
         ops.set_workspace(self._splitk_ws)
         if "LCM_CONV_IMPL" in os.environ:            # A/B switches for kernel work
             ops.set_conv_impl(int(os.environ["LCM_CONV_IMPL"]))
+        if "LCM_GN_FUSED_BYTES" in os.environ:
+            ops.set_gn_fused_bytes(int(os.environ["LCM_GN_FUSED_BYTES"]))
         if "LCM_PERSIST_N" in os.environ:
             ops.set_persist_n(int(os.environ["LCM_PERSIST_N"]))
         if "LCM_HALO_PIPE" in os.environ:

@@ -185,8 +185,17 @@ def test_fused_groupnorm_stats_from_conv(B, H, W, Cin, Cout, splitk, stride):
     y = torch.empty_like(out)
     ws = torch.empty(ops.groupnorm_ws_bytes(B, HW, Cout) // 4 + 16, dtype=torch.float32, device=DEV)
     if st.P > 0:
-        ops.groupnorm_from_stats(out, gamma.to(DEV), beta.to(DEV), y, B, HW, Cout, st, ws)
-        close(y, ref, what=f"gn from fused stats (P={st.P})")
+        ys = []
+        try:
+            for fused_bytes in (0, 1 << 40):            # two launches (finalize + apply) vs the single small-tensor launch
+                ops.set_gn_fused_bytes(fused_bytes)
+                y = torch.empty_like(out)
+                ops.groupnorm_from_stats(out, gamma.to(DEV), beta.to(DEV), y, B, HW, Cout, st, ws)
+                close(y, ref, what=f"gn from fused stats (P={st.P}, single-launch limit {fused_bytes})")
+                ys.append(y)
+        finally:
+            ops.set_gn_fused_bytes(8 << 20)
+        assert torch.equal(ys[0], ys[1])                # same arithmetic, same order
     else:
         assert HW % 64 != 0, "statistics should have been produced for this shape"
 
@@ -214,8 +223,13 @@ def test_fused_groupnorm_stats_concat_and_gemm():
     ref = _ref_gn(torch.cat([x1.cpu(), x2.cpu()], 1), B, HW, C, gamma, beta, 1e-5, True)
     y = torch.empty(B * HW, C, dtype=torch.float16, device=DEV)
     ws = torch.empty(ops.groupnorm_ws_bytes(B, HW, C) // 4 + 16, dtype=torch.float32, device=DEV)
-    ops.groupnorm_from_stats(x1, gamma.to(DEV), beta.to(DEV), y, B, HW, C1, st1, ws, x2=x2, C2=C2, st2=st2)
-    close(y, ref, what="gn from fused stats over a concat")
+    try:
+        for fused_bytes in (0, 1 << 40):
+            ops.set_gn_fused_bytes(fused_bytes)
+            ops.groupnorm_from_stats(x1, gamma.to(DEV), beta.to(DEV), y, B, HW, C1, st1, ws, x2=x2, C2=C2, st2=st2)
+            close(y, ref, what=f"gn from fused stats over a concat (single-launch limit {fused_bytes})")
+    finally:
+        ops.set_gn_fused_bytes(8 << 20)
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,ups,splitk", [(2, 12, 20, 128, 192, 0, False), (1, 9, 7, 64, 64, 0, False),
