@@ -213,17 +213,23 @@ __device__ __forceinline__ void halo_wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int TH, int TW, int BN, int WS, int PH>
+// TPS = taps per K-step: 1, or one whole kernel row (3; 2 for the 2x2 phase kernels).  Measured on the batch-1 launches
+// (one wave per SIMD, tools/trace_conv.py): a one-tap step costs ~900 cycles for 8-16 MFMAs per wave -- barrier, LDS-DMA
+// issue and two exposed ds_read latencies -- because nothing may cross the barrier; with a row of taps per step the
+// ds_reads of tap i+1 run under the MFMAs of tap i and there is one barrier per row.
+template <int TH, int TW, int BN, int WS, int PH, int TPS>
 __global__ __launch_bounds__(256, 2) void conv_halo_pipe_kernel(HaloParams hp) {
     constexpr int NT = PH ? 4 : 9;
+    constexpr int G = NT / TPS;            // K-steps per 64-channel chunk
+    static_assert(TPS == 1 || TPS == (PH ? 2 : 3), "taps per step: 1 or one kernel row");
     constexpr int BM = TH * TW;
     constexpr int TM = BM / 32, TN = BN / 32, RW = BN / 32;
     constexpr int HWD = TW + 2, HROWS = (TH + 2) * HWD, HROWS_PAD = (HROWS + 7) / 8 * 8;
     constexpr int NV = (HROWS_PAD * 8 + 255) / 256;
-    constexpr int XBYTES = HROWS_PAD * 128, WBYTES = BN * 128;
+    constexpr int XBYTES = HROWS_PAD * 128, WBYTES = BN * 128, SBYTES = TPS * WBYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* xs0 = smem;                      // two halo buffers
-    char* wsm0 = smem + 2 * XBYTES;        // WS weight-slice buffers
+    char* wsm0 = smem + 2 * XBYTES;        // WS weight-step buffers (TPS tap slices each)
 
     const IgemmParams& p = hp.g;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -270,7 +276,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_pipe_kernel(HaloParams hp) {
     const int nchunks = p.Cin >> 6;
     const int c_begin = (int)((long long)blockIdx.y * nchunks / p.splits);
     const int c_end = (int)((long long)(blockIdx.y + 1) * nchunks / p.splits);
-    const int T = (c_end - c_begin) * NT;
+    const int T = (c_end - c_begin) * G;
 
     auto issue_halo = [&](int c64, int hb) {
         const int cb = c64 << 6;
@@ -291,14 +297,17 @@ __global__ __launch_bounds__(256, 2) void conv_halo_pipe_kernel(HaloParams hp) {
             }
         }
     };
-    auto issue_w = [&](int t, int wb) {     // t = flattened (chunk, tap) step
-        const int c64 = c_begin + t / NT, tap = t - (t / NT) * NT;
-        const half_t* wsrc = wptr + (long long)tap * p.Cin + (c64 << 6);
-        char* wsm = wsm0 + wb * WBYTES;
+    auto issue_w = [&](int t, int wb) {     // t = flattened (chunk, tap group) step
+        const int c64 = c_begin + t / G, tg = t - (t / G) * G;
 #pragma unroll
-        for (int i = 0; i < RW; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + (long long)(32 * i) * p.K),
-                                             (__attribute__((address_space(3))) void*)(wsm + (i * 32 + wave * 8) * 128), 16, 0, 0);
+        for (int tp = 0; tp < TPS; ++tp) {
+            const half_t* wsrc = wptr + (long long)(tg * TPS + tp) * p.Cin + (c64 << 6);
+            char* wsm = wsm0 + wb * SBYTES + tp * WBYTES;
+#pragma unroll
+            for (int i = 0; i < RW; ++i)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc + (long long)(32 * i) * p.K),
+                                                 (__attribute__((address_space(3))) void*)(wsm + (i * 32 + wave * 8) * 128), 16, 0, 0);
+        }
     };
 
     // prologue: halo of the first chunk, then WS-1 weight slices
@@ -308,40 +317,80 @@ __global__ __launch_bounds__(256, 2) void conv_halo_pipe_kernel(HaloParams hp) {
         if (s < T) issue_w(s, s);
 
     int wb = 0;
+    constexpr int LPS = RW * TPS;          // LDS-DMA instructions per thread per K-step
     for (int t = 0; t < T; ++t) {
-        const int chunk = t / NT, tap = t - chunk * NT;
-        // W(t) (and, being older, this chunk's halo) must have landed; min(WS-2, T-1-t) newer slices may stay in flight
+        const int chunk = t / G, tg = t - chunk * G;
+        // W(t) (and, being older, this chunk's halo) must have landed; min(WS-2, T-1-t) newer steps may stay in flight
         const int newer = T - 1 - t;
-        if (WS >= 4 && newer >= 2) halo_wait_vmcnt<(WS >= 4 ? 2 : 0) * RW>();
-        else if (WS >= 3 && newer >= 1) halo_wait_vmcnt<(WS >= 3 ? 1 : 0) * RW>();
+        if (WS >= 4 && newer >= 2) halo_wait_vmcnt<(WS >= 4 ? 2 : 0) * LPS>();
+        else if (WS >= 3 && newer >= 1) halo_wait_vmcnt<(WS >= 3 ? 1 : 0) * LPS>();
         else halo_wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         if (t + WS - 1 < T) issue_w(t + WS - 1, (wb + WS - 1) % WS);
-        if (tap == 0 && c_begin + chunk + 1 < c_end) issue_halo(c_begin + chunk + 1, (chunk + 1) & 1);
+        if (tg == 0 && c_begin + chunk + 1 < c_end) issue_halo(c_begin + chunk + 1, (chunk + 1) & 1);
 
         const char* xs = xs0 + (chunk & 1) * XBYTES;
-        const int dy = PH ? (tap >> 1) + py : tap / 3, dx = PH ? (tap & 1) + px : tap - (tap / 3) * 3;
-        const int tapoff = dy * HWD + dx;
-        const char* wsr = wsm0 + wb * WBYTES + (wn * (BN / 2)) * 128;
+        if constexpr (TPS == 1) {
+            const int tap = tg;
+            const int dy = PH ? (tap >> 1) + py : tap / 3, dx = PH ? (tap & 1) + px : tap - (tap / 3) * 3;
+            const int tapoff = dy * HWD + dx;
+            const char* wsr = wsm0 + wb * SBYTES + (wn * (BN / 2)) * 128;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            h8 xf[TM], wf[TN];
-            const int c = kk * 4 + fq;
+            for (int kk = 0; kk < 2; ++kk) {
+                h8 xf[TM], wf[TN];
+                const int c = kk * 4 + fq;
 #pragma unroll
-            for (int b = 0; b < TM; ++b) {
-                const int r = rb0 + b * RB_STEP + tapoff;
-                xf[b] = *reinterpret_cast<const h8*>(xs + r * 128 + ((c ^ (r & 7)) << 4));
+                for (int b = 0; b < TM; ++b) {
+                    const int r = rb0 + b * RB_STEP + tapoff;
+                    xf[b] = *reinterpret_cast<const h8*>(xs + r * 128 + ((c ^ (r & 7)) << 4));
+                }
+#pragma unroll
+                for (int a = 0; a < TN; ++a) {
+                    const int r = a * 16 + frow;
+                    wf[a] = *reinterpret_cast<const h8*>(wsr + r * 128 + ((c ^ (r & 7)) << 4));
+                }
+#pragma unroll
+                for (int a = 0; a < TN; ++a)
+#pragma unroll
+                    for (int b = 0; b < TM; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[a], xf[b], acc[a][b], 0, 0, 0);
             }
+        } else {
+            // a row of taps per step, software-pipelined over the taps: the fragments of tap i+1 are fetched from LDS
+            // while the MFMAs of tap i run (one wave per SIMD has nobody else to hide the ds_read latency behind)
+            h8 xf[2][2][TM], wf[2][2][TN];
+            auto load_frags = [&](int tp, int buf) {
+                const int tapoff = (tg + (PH ? py : 0)) * HWD + tp + (PH ? px : 0);
+                const char* wsr = wsm0 + wb * SBYTES + tp * WBYTES + (wn * (BN / 2)) * 128;
 #pragma unroll
-            for (int a = 0; a < TN; ++a) {
-                const int r = a * 16 + frow;
-                wf[a] = *reinterpret_cast<const h8*>(wsr + r * 128 + ((c ^ (r & 7)) << 4));
+                for (int kk = 0; kk < 2; ++kk) {
+                    const int c = kk * 4 + fq;
+#pragma unroll
+                    for (int b = 0; b < TM; ++b) {
+                        const int r = rb0 + b * RB_STEP + tapoff;
+                        xf[buf][kk][b] = *reinterpret_cast<const h8*>(xs + r * 128 + ((c ^ (r & 7)) << 4));
+                    }
+#pragma unroll
+                    for (int a = 0; a < TN; ++a) {
+                        const int r = a * 16 + frow;
+                        wf[buf][kk][a] = *reinterpret_cast<const h8*>(wsr + r * 128 + ((c ^ (r & 7)) << 4));
+                    }
+                }
+            };
+            load_frags(0, 0);
+#pragma unroll
+            for (int tp = 0; tp < TPS; ++tp) {
+                if (tp + 1 < TPS) load_frags(tp + 1, (tp + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int a = 0; a < TN; ++a)
+#pragma unroll
+                        for (int b = 0; b < TM; ++b)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[tp & 1][kk][a], xf[tp & 1][kk][b], acc[a][b], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
-#pragma unroll
-            for (int a = 0; a < TN; ++a)
-#pragma unroll
-                for (int b = 0; b < TM; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[a], xf[b], acc[a][b], 0, 0, 0);
         }
         wb = (wb + 1 == WS) ? 0 : wb + 1;
     }
@@ -368,25 +417,44 @@ static int g_halo_pipe_below = 768;      // workgroup count under which the pipe
 extern "C" int lcm_set_halo_pipe_threshold(int wgs) { g_halo_pipe_below = wgs; return LCM_OK; }
 
 template <int TH, int TW, int BN, int XFORM, int PH>
-static void launch_halo(HaloParams& hp, hipStream_t s, int force) {     // force: 1 single-buffer, 2 pipelined, else by grid size
+static void launch_halo(HaloParams& hp, hipStream_t s, int force) {     // force: 1 single-buffer, 2 pipelined, 3 pipelined with a row of taps per step, else by grid size
     constexpr int HROWS_PAD = ((TH + 2) * (TW + 2) + 7) / 8 * 8;
     hp.tiles_y = ((PH ? hp.g.Hin : hp.H) + TH - 1) / TH;
     hp.tiles_x = ((PH ? hp.g.Win : hp.W) + TW - 1) / TW;
     hp.g.ntiles = hp.g.N / BN;
     dim3 grid(hp.g.mtiles * hp.g.ntiles, hp.g.splits, 1);
-    if (!XFORM && force != 1 && (force == 2 || (long long)grid.x * grid.y < g_halo_pipe_below)) {
-        constexpr int WS = 3;
-        constexpr int smem = 2 * HROWS_PAD * 128 + WS * BN * 128;
+    if constexpr (!XFORM && BN <= 128) if (force == 3) {
+        // one kernel row of taps per K-step (plan variant 3): batch-1 launches, one workgroup per CU
+        constexpr int TPS = PH ? 2 : 3;
+        constexpr int WS = BN == 64 ? 3 : 2;
+        constexpr int smem = 2 * HROWS_PAD * 128 + WS * TPS * BN * 128;
+        static_assert(smem <= 160 * 1024, "row-step halo ring exceeds LDS");
         static bool attr_set = false;
         if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_pipe_kernel<TH, TW, BN, WS, PH>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_pipe_kernel<TH, TW, BN, WS, PH, TPS>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem);
             attr_set = true;
         }
         char nm[64];
-        snprintf(nm, sizeof(nm), "conv_halo_pipe_kernel<%d, %d, %d, %d, %d>%s", TH, TW, BN, WS, PH, hp.g.splits > 1 ? " +splitk" : "");
+        snprintf(nm, sizeof(nm), "conv_halo_pipe_kernel<%d, %d, %d, %d, %d, %d>%s", TH, TW, BN, WS, PH, TPS, hp.g.splits > 1 ? " +splitk" : "");
         lcm_prof_start(nm, s);
-        hipLaunchKernelGGL((conv_halo_pipe_kernel<TH, TW, BN, WS, PH>), grid, dim3(256), smem, s, hp);
+        hipLaunchKernelGGL((conv_halo_pipe_kernel<TH, TW, BN, WS, PH, TPS>), grid, dim3(256), smem, s, hp);
+        lcm_prof_stop(s);
+        return;
+    }
+    if (!XFORM && force != 1 && (force == 2 || force == 3 || (long long)grid.x * grid.y < g_halo_pipe_below)) {
+        constexpr int WS = 3;
+        constexpr int smem = 2 * HROWS_PAD * 128 + WS * BN * 128;
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_pipe_kernel<TH, TW, BN, WS, PH, 1>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            attr_set = true;
+        }
+        char nm[64];
+        snprintf(nm, sizeof(nm), "conv_halo_pipe_kernel<%d, %d, %d, %d, %d, 1>%s", TH, TW, BN, WS, PH, hp.g.splits > 1 ? " +splitk" : "");
+        lcm_prof_start(nm, s);
+        hipLaunchKernelGGL((conv_halo_pipe_kernel<TH, TW, BN, WS, PH, 1>), grid, dim3(256), smem, s, hp);
         lcm_prof_stop(s);
         return;
     }
@@ -439,7 +507,7 @@ int lcm_conv_halo_launch(HaloParams& hp, int B, hipStream_t s, int* slabs_per_im
             !(TW == 8 && pbm == 128)) {
             if (psp > 1 && (!p.ws || (long long)psp * p.M * p.N * 4 > ws_bytes || psp > nchunks)) psp = 1;
             bm = pbm; bn = pbn; splits = psp;
-            force = (pv == 1 || pv == 2) ? pv : 0;
+            force = (pv >= 1 && pv <= 3) ? pv : 0;
         }
     }
     if (!bm) return 1;

@@ -257,6 +257,25 @@ def test_conv_halo_pipelined_variant_is_bit_identical(B, H, W, Cin, Cout, ups, s
         ops.set_halo_pipe_threshold(768)
         ops.set_workspace(None)
     assert torch.equal(outs[0], outs[1])
+    # plan variant 3: a whole kernel row of taps per K-step -- same K order, bit-identical again
+    from sdlcm_amd import lib as _l
+    for bm, bn in ((128, 64), (64, 64), (128, 128), (64, 128)):
+        if Cout % bn or (min(Ho, Wo) <= 8 and bm == 128):
+            continue
+        ops.set_workspace(ws if splitk else None)
+        try:
+            pair = []
+            for var in (2, 3):
+                ops.plan_clear()
+                ops.plan_set(2, B * Ho * Wo, Cout, 9 * Cin, Wo << 1, bm, bn, 2 if (splitk and Cin >= 128) else 1, var)
+                o = torch.empty(B * Ho * Wo, Cout, dtype=torch.float16, device=DEV)
+                ops.conv3x3(x, w, o, B, H, W, Cin, Cout, bias=b, ups=ups)
+                pair.append(o)
+            torch.cuda.synchronize()
+        finally:
+            ops.plan_clear()
+            ops.set_workspace(None)
+        assert torch.equal(pair[0], pair[1]), f"row-step variant differs at tile {bm}x{bn}"
     xin = from_nhwc(x.cpu().float(), B, H, W)
     if ups:
         xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
@@ -293,6 +312,20 @@ def test_conv_upsample_phase_decomposition(B, H, W, Cin, Cout, splitk):
         ops.set_halo_pipe_threshold(768)
         ops.set_workspace(None)
     assert torch.equal(outs[0], outs[1])
+    if H >= 6 and W >= 6:      # plan variant 3 (a row of the 2x2 taps per K-step) against variant 2, bitwise
+        pair = []
+        try:
+            for var in (2, 3):
+                ops.plan_clear()
+                ops.plan_set(2, B * Ho * Wo, Cout, 4 * Cin, Wo << 1, 64, 64, 1, var)
+                o = torch.empty(B * Ho * Wo, Cout, dtype=torch.float16, device=DEV)
+                ops.conv3x3(x, wp, o, B, H, W, Cin, Cout, bias=b, ups=2)
+                pair.append(o)
+            torch.cuda.synchronize()
+        finally:
+            ops.plan_clear()
+        assert torch.equal(pair[0], pair[1])
+        close(pair[1], outs[0], what="row-step phase conv vs default plan")
     xin = F.interpolate(from_nhwc(x.cpu().float(), B, H, W), scale_factor=2.0, mode="nearest")
     ref = F.conv2d(xin, w4.float(), b.cpu().float(), padding=1)
     close(from_nhwc(outs[1], B, Ho, Wo), ref, what="phase-decomposed upsample conv")

@@ -54,7 +54,7 @@ for (B, H, Cin, Cout) in [(1, 64, 320, 320), (1, 32, 640, 640), (1, 16, 1280, 12
             for sp in (1, 2, 3, 4, 5, 8, 10, 20):
                 if sp > Cin // 64:
                     continue
-                for var in (1, 2):
+                for var in (1, 2, 3):
                     ops.plan_clear()
                     ops.plan_set(2, M, Cout, 9 * Cin, H << 1, bm, bn, sp, var)
                     fns = [(lambda i=i: ops.conv3x3(x[i % 2], Ws[i], o[i % 2], B, H, H, Cin, Cout, bias=bias)) for i in range(nset)]
