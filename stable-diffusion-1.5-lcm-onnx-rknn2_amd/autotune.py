@@ -50,9 +50,9 @@ def _candidates(key, meta, ws_bytes, cold=False):
             # the library's occupancy rule picks it (csrc/igemm.hip launch_cfg)
             # ... unless the timing itself runs cold (small-batch plans, see autotune(cold=True)): then the depth is a
             # fair candidate for the GEMM kernels
-            # (GEMM: LDS ring depth 1/2/4; halo conv: 1 = single-buffer, 2 = pipelined weight ring, 3 = pipelined with a
+            # (GEMM: 0 = register-staged double buffer, LDS-DMA ring depth 1/2/4; halo conv: 1 = single-buffer, 2 = pipelined weight ring, 3 = pipelined with a
             # whole kernel row of taps per K-step -- 64/128-wide tiles only)
-            variants = ((-1, 1, 2, 4) if kind == 0 else ((1, 2, 3) if bn <= 128 else (1, 2)) if meta["halo"] else (-1,)) if cold else (-1,)
+            variants = ((-1, 0, 1, 2, 4) if kind == 0 else ((1, 2, 3) if bn <= 128 else (1, 2)) if meta["halo"] else (-1,)) if cold else (-1,)
             for v in variants:
                 out.append((bm, bn, s, v))
     return out
