@@ -243,3 +243,48 @@ def test_microbatcher_errors_reach_every_waiter_and_window():
             f.result(5)
     assert mb.submit("k", 3).result(5) == 3                 # the dispatcher survives a failed pass
     mb.close()
+
+
+def test_upsample_phase_packing_matches_interpolate_then_conv():
+    """packing.pack_conv3x3_up2: nearest-2x upsample -> conv3x3 == four 2x2 phase convolutions on the low-resolution
+    input with the coinciding taps summed (SURVEY A.5 Upsample2D); checked in fp32 against the torch op order."""
+    import torch
+    import torch.nn.functional as F
+    from sdlcm_amd.packing import pack_conv3x3_up2
+    g = torch.Generator().manual_seed(0)
+    Cin, Cout, H, W = 8, 6, 5, 7
+    w = torch.randn(Cout, Cin, 3, 3, generator=g)
+    x = torch.randn(2, Cin, H, W, generator=g)
+    ref = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), w, padding=1)
+    wp = pack_conv3x3_up2(w).reshape(4, Cout, 2, 2, Cin)
+    xp = F.pad(x, (1, 1, 1, 1))
+    out = torch.zeros_like(ref)
+    for py in range(2):
+        for px in range(2):
+            acc = torch.zeros(2, Cout, H, W)
+            for dy in range(2):
+                for dx in range(2):
+                    acc += torch.einsum("bchw,oc->bohw", xp[:, :, py + dy:py + dy + H, px + dx:px + dx + W], wp[py * 2 + px, :, dy, dx, :])
+            out[:, :, py::2, px::2] = acc
+    assert (out - ref).abs().max() < 1e-4
+
+
+def test_plan_table_sources_and_gn_fusion_rule(tmp_path, monkeypatch):
+    """Launch plans: the shipped table is read unless LCM_TUNED_PLANS=0, a user LCM_TUNE_CACHE file overlays it; the
+    GroupNorm-into-conv fusion rule only fires for tensors beyond the Infinity Cache and convs with few n-tiles."""
+    import json
+    from sdlcm_amd import autotune, model
+    shipped = autotune._load_cache()
+    assert len(shipped) > 100 and all(len(k) == 5 and v[0] in (64, 128) and v[1] in (64, 128, 160) for k, v in shipped.items())
+    key = next(iter(shipped))
+    user = tmp_path / "plans.json"
+    user.write_text(json.dumps({",".join(str(x) for x in key): [64, 64, 1, -1, 0.5], "0,7,64,64,1": [64, 64, 1, -1, 0.1]}))
+    monkeypatch.setenv("LCM_TUNE_CACHE", str(user))
+    merged = autotune._load_cache()
+    assert tuple(merged[key][:4]) == (64, 64, 1, -1) and (0, 7, 64, 64, 1) in merged and len(merged) == len(shipped) + 1
+    monkeypatch.setenv("LCM_TUNED_PLANS", "0")
+    assert set(autotune._load_cache()) == {key, (0, 7, 64, 64, 1)}
+    assert model._fuse_gn_into_conv(8 * 512 * 512, 128, 128)            # VAE 512^2 level at batch 8: 537 MB, one n-tile
+    assert model._fuse_gn_into_conv(512 * 512, 128, 128)                # ... and at batch 1 (67 MB)
+    assert not model._fuse_gn_into_conv(4096, 320, 320)                 # batch-1 UNet level: 2.6 MB, served from cache
+    assert not model._fuse_gn_into_conv(8 * 128 * 128, 512, 512)        # 4 n-tiles of 128: the transform would repeat 4x
