@@ -153,7 +153,7 @@ def main():
     dev = f"cuda:{local}"
     if args.model == "sdxl":
         from sdlcm_amd.config import SDXL_UNET, unet_config, vae_config
-        ucfg, vcfg = unet_config(SDXL_UNET), vae_config(dict(scaling_factor=0.13025, sample_size=1024))
+        ucfg, vcfg = unet_config(SDXL_UNET), vae_config(dict(scaling_factor=0.13025, sample_size=1024, force_upcast=True))
         pipe = LcmHipPipeline(weights.synthetic_state_dict(weights.unet_param_spec(ucfg), 0),
                               weights.synthetic_state_dict(weights.vae_param_spec(vcfg), 1), ucfg, vcfg, device=dev)
     else:

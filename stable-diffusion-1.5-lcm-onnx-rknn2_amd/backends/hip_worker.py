@@ -158,6 +158,10 @@ class HipLcmWorker:
                                    "(SD1.5: 768/1024, SDXL: 2048)")                  # cuda_worker.py:114-116
             sched = LCMSchedule.from_config_file(os.path.join(ckpt, "scheduler", "scheduler_config.json"))
             ckpt_root = ckpt if format_name == "diffusers" else None
+        if self.FAMILY == "sd15" and vcfg is not None:
+            # only the SDXL pipeline honours the VAE's force_upcast (StableDiffusionXLPipeline.upcast_vae); SD1.5 decodes in
+            # the pipeline dtype whatever the checkpoint's vae/config.json says
+            vcfg = dict(vcfg, force_upcast=False, residual_scale=1.0)
         self.pipe = LcmHipPipeline(usd, vsd, ucfg, vcfg, device=device, schedule=sched)
         with torch.cuda.stream(self.pipe.stream):
             self._load_text_encoders(device, ckpt_root, clip_sd)
@@ -354,7 +358,7 @@ class HipLcmSDXLWorker(HipLcmWorker):
     def _synthetic_weights(self):
         from ..config import SDXL_UNET, unet_config, vae_config
         ucfg = unet_config(SDXL_UNET)
-        vcfg = vae_config(dict(scaling_factor=0.13025, sample_size=1024))
+        vcfg = vae_config(dict(scaling_factor=0.13025, sample_size=1024, force_upcast=True))
         return (_weights.synthetic_state_dict(_weights.unet_param_spec(ucfg), 0), ucfg,
                 _weights.synthetic_state_dict(_weights.vae_param_spec(vcfg), 1), vcfg)
 

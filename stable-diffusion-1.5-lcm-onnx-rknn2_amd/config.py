@@ -27,6 +27,8 @@ SDXL_UNET = dict(
 SD15_VAE = dict(
     latent_channels=4, out_channels=3, block_out_channels=(128, 256, 512, 512),
     layers_per_block=2, norm_num_groups=32, scaling_factor=0.18215, sample_size=512,
+    force_upcast=False,        # SDXL VAE: True -> the decoder runs with its residual stream scaled by 1/16 (model.py)
+    residual_scale=1.0,
 )
 
 TEXT_SEQ_LEN = 77          # CLIP model_max_length (backends/rknnlcm.py:305-312)
@@ -60,4 +62,6 @@ def vae_config(overrides: dict | None = None) -> dict:
     c = dict(SD15_VAE)
     if overrides:
         c.update(overrides)
+    if c.get("force_upcast") and float(c.get("residual_scale", 1.0)) == 1.0:
+        c["residual_scale"] = 1.0 / 16.0       # the fp16 stand-in for the reference's fp32 upcast of the SDXL VAE
     return c

@@ -385,12 +385,46 @@ class UNetHip(_Net):
         return eps_out
 
 
+def scale_vae_residual_stream(sd: dict, cfg: dict, s: float) -> dict:
+    """Exact reparametrisation of the AutoencoderKL decoder that shrinks its residual stream by ``s`` (< 1).
+
+    The SDXL VAE overflows fp16 in its up blocks, which is why the reference pipeline upcasts it to fp32
+    (``force_upcast`` in the checkpoint's vae/config.json; StableDiffusionXLPipeline.upcast_vae, reached from
+    backends/cuda_worker.py:330-352).  Every consumer of the decoder's residual stream is a GroupNorm -- invariant to
+    the scale of its input (up to eps) -- or a linear op followed by one, so the stream can carry s*x instead of x:
+    scale what WRITES into it (conv_in, each resnet's conv2, the attention's to_out) by s, scale the BIAS of the
+    linear ops that map stream to stream (conv_shortcut, upsampler conv) by s, leave everything else alone; the final
+    conv_norm_out removes the factor again.  Same function, activations 1/s smaller, no fp32 pass needed."""
+    out = dict(sd)
+
+    def mul(name):
+        out[name] = (sd[name].float() * s).to(sd[name].dtype)
+
+    for n in ("decoder.conv_in.weight", "decoder.conv_in.bias", "decoder.mid_block.attentions.0.to_out.0.weight",
+              "decoder.mid_block.attentions.0.to_out.0.bias"):
+        mul(n)
+    resnets = ["decoder.mid_block.resnets.0", "decoder.mid_block.resnets.1"]
+    nb = len(cfg["block_out_channels"])
+    for i in range(nb):
+        resnets += [f"decoder.up_blocks.{i}.resnets.{j}" for j in range(cfg["layers_per_block"] + 1)]
+        if i < nb - 1:
+            mul(f"decoder.up_blocks.{i}.upsamplers.0.conv.bias")
+    for r in resnets:
+        mul(r + ".conv2.weight")
+        mul(r + ".conv2.bias")
+        if r + ".conv_shortcut.bias" in sd:
+            mul(r + ".conv_shortcut.bias")
+    return out
+
+
 # ==================================================================================================
 class VAEDecoderHip(_Net):
     def __init__(self, sd: dict, cfg: dict | None = None, device="cuda"):
         super().__init__(device)
         self.cfg = cfg = vae_config(cfg)
         boc = cfg["block_out_channels"]
+        if float(cfg.get("residual_scale", 1.0)) != 1.0:
+            sd = scale_vae_residual_stream(sd, cfg, float(cfg["residual_scale"]))
         self._put("pq.w", sd["post_quant_conv.weight"].reshape(4, 4), torch.float32)
         self._put("pq.b", sd["post_quant_conv.bias"], torch.float32)
         self._put("conv_in.w", pack_conv3x3(sd["decoder.conv_in.weight"]))

@@ -444,7 +444,7 @@ def load_single_file_sdxl(path: str):
                             projection_class_embeddings_input_dim=usd["add_embedding.linear_1.weight"].shape[1]))
     vboc = (vsd["decoder.up_blocks.3.resnets.0.conv1.weight"].shape[0], vsd["decoder.up_blocks.2.resnets.0.conv1.weight"].shape[0],
             vsd["decoder.up_blocks.1.resnets.0.conv1.weight"].shape[0], vsd["decoder.conv_in.weight"].shape[0])
-    vcfg = vae_config(dict(block_out_channels=vboc, scaling_factor=0.13025, sample_size=1024))
+    vcfg = vae_config(dict(block_out_channels=vboc, scaling_factor=0.13025, sample_size=1024, force_upcast=True))
     for what, sd, spec in (("unet", usd, unet_param_spec(ucfg)), ("vae", vsd, vae_param_spec(vcfg))):
         for name, shape, _ in spec:
             if name not in sd:

@@ -81,6 +81,45 @@ def test_vae_decode_parity(state):
     assert np.abs(rgb.cpu().numpy().astype(int) - u8.astype(int)).max() <= 3
 
 
+def test_vae_residual_stream_rescaling_matches_fp32_reference_where_fp16_overflows(state):
+    """SDXL VAE ``force_upcast``: the reference decodes it in fp32 because the decoder's residual stream overflows fp16.
+    The HIP decoder instead carries the stream scaled by 1/16 (exact reparametrisation, model.scale_vae_residual_stream).
+    (1) plain weights: scaled == unscaled == oracle within tolerance; (2) weights whose residual stream reaches ~1e5:
+    the unscaled fp16 decoder produces non-finite / wrong pixels, the scaled one still matches the fp32 oracle."""
+    from sdlcm_amd.model import VAEDecoderHip
+    from oracle.vae import VAEDecoderOracle
+    hip, ora = state["hip"], state["ora"]
+    B, h, w = 1, 16, 16
+    lat = torch.randn(B, 4, h, w, generator=torch.Generator().manual_seed(11)) * 0.9
+    base_sd = {k: v.clone() for k, v in ora.vae.sd.items()}
+    for boost in (1.0, 6000.0):
+        sd = dict(base_sd)
+        if boost != 1.0:       # blow up the stream at its source; GroupNorms keep everything downstream of them O(1)
+            sd["decoder.conv_in.weight"] = base_sd["decoder.conv_in.weight"] * boost
+            sd["decoder.conv_in.bias"] = base_sd["decoder.conv_in.bias"] * boost
+        ref = VAEDecoderOracle(sd, ora.vae.cfg).decode(lat).numpy()
+        sd16 = {k: v.to(torch.float16) for k, v in sd.items()}
+        imgs = {}
+        for scale in (1.0, 1.0 / 16.0):
+            cfg = dict(hip.vae.cfg, residual_scale=scale, force_upcast=False)
+            with torch.cuda.stream(hip.stream):
+                dec = VAEDecoderHip(sd16, cfg, device=hip.device)
+                rgb = torch.zeros(B, 8 * h, 8 * w, 3, dtype=torch.uint8, device=hip.device)
+                img = torch.zeros(B, 8 * h, 8 * w, 3, dtype=torch.float32, device=hip.device)
+                dec.decode(lat.to(hip.device), B, h, w, rgb, img_f32=img)
+                hip.stream.synchronize()
+            imgs[scale] = np.clip(img.cpu().numpy().transpose(0, 3, 1, 2) / 2 + 0.5, 0, 1)
+        r01 = np.clip(ref / 2 + 0.5, 0, 1)
+        e_scaled = np.abs(imgs[1.0 / 16.0] - r01)
+        e_plain = np.abs(np.nan_to_num(imgs[1.0], nan=9.0) - r01)
+        print(f"boost {boost}: max err scaled {e_scaled.max():.4g}, unscaled {e_plain.max():.4g}")
+        assert np.isfinite(imgs[1.0 / 16.0]).all() and e_scaled.max() < 1e-2
+        if boost == 1.0:
+            assert e_plain.max() < 1e-2
+        else:
+            assert e_plain.max() > 5e-2          # the un-rescaled fp16 decoder really does break on these weights
+
+
 @pytest.mark.parametrize("h,w", [(48, 40), (32, 72), (56, 56)])
 def test_vae_tiled_decode_parity(state, h, w):
     """vae.enable_tiling() (backends/cuda_worker.py:91): latents larger than sample_size/8 take diffusers' overlapping
