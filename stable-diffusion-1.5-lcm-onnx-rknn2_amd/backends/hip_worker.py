@@ -186,7 +186,7 @@ class HipLcmWorker:
 
     # ---- style LoRAs (backends/cuda_worker.py:123-196) -----------------------------------------
     def _load_styles(self):
-        from ..lora import LoraStyle
+        from ..lora import StyleAdapters
         from .styles import STYLE_REGISTRY
         cad = int(self.pipe.unet.ctx_dim)
         for sid, sd in STYLE_REGISTRY.items():
@@ -200,10 +200,10 @@ class HipLcmWorker:
             try:
                 from safetensors.torch import load_file
                 with torch.cuda.stream(self.pipe.stream):
-                    st = LoraStyle(self.pipe.unet, load_file(path))
+                    st = StyleAdapters(self.pipe.unet, self._text_encoders(), load_file(path))
                 self._styles[sid] = st
-                print(f"[hip] loaded style LoRA: {sid} -> {path} ({len(st.modules)} modules, {len(st.skipped)} tensors skipped, "
-                      f"{st.nbytes() / 1e6:.0f} MB)")
+                print(f"[hip] loaded style LoRA: {sid} -> {path} ({len(st.modules)} UNet + {st.text_modules} text-encoder modules, "
+                      f"{len(st.skipped)} tensors skipped, {st.nbytes() / 1e6:.0f} MB)")
             except Exception as e:
                 print(f"[hip] FAILED to load style LoRA {sid}: {e!r}")
 
@@ -236,6 +236,9 @@ class HipLcmWorker:
         self._encode = HipPromptEncoder(device, ckpt_root, clip_sd)
         if self._encode.enc.D != self.pipe.unet.ctx_dim:
             raise RuntimeError(f"text encoder width {self._encode.enc.D} != UNet cross_attention_dim {self.pipe.unet.ctx_dim}")
+
+    def _text_encoders(self):
+        return [self._encode.enc]
 
     def _text_bytes(self):
         return self._encode.enc.weight_bytes()
@@ -387,6 +390,9 @@ class HipLcmSDXLWorker(HipLcmWorker):
             self._tok.append(_BpeTokenizer(td) if td and os.path.isdir(td) else HashTokenizer(cfg["vocab_size"]))
         if self._enc[0].D + self._enc[1].D != self.pipe.unet.ctx_dim:
             raise RuntimeError("text encoder widths do not add up to the UNet cross_attention_dim")
+
+    def _text_encoders(self):
+        return list(self._enc)
 
     def _text_bytes(self):
         return sum(e.weight_bytes() for e in self._enc)

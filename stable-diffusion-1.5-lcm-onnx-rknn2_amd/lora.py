@@ -7,7 +7,10 @@ W' = W + weight * delta IN PLACE with the ``lcm_axpy_f16`` kernel, so captured h
 
 Supported targets: every Linear / 1x1-conv of the transformer blocks (proj_in/out, attn1/attn2 to_q/k/v/out, ff);
 key styles: kohya (``lora_unet_<path>.lora_down.weight`` / ``.lora_up.weight`` / ``.alpha``) and peft / diffusers
-(``unet.<path>.lora_A.weight`` / ``.lora_B.weight``).  Conv (LoCon) and text-encoder LoRA entries are reported and skipped.
+(``unet.<path>.lora_A.weight`` / ``.lora_B.weight``).  Text-encoder entries (``lora_te_`` / ``lora_te1_`` / ``lora_te2_`` /
+``text_encoder[_2].``: the q/k/v/out projections and the MLP of every CLIP layer) are merged into the native CLIP
+encoders the same way (``ClipLora``), as ``pipe.load_lora_weights`` does for the reference.  Conv (LoCon) entries are
+reported and skipped.
 """
 from __future__ import annotations
 
@@ -120,3 +123,89 @@ class LoraStyle:
         for n, d in self.delta.items():
             ops.axpy(self.base[n], d, weight, self.unet.w[n])
         self.current = weight
+
+
+# ---- text-encoder LoRA ---------------------------------------------------------------------------
+_TE_SUB = {"self_attn.q_proj": ("qkv", 0), "self_attn.k_proj": ("qkv", 1), "self_attn.v_proj": ("qkv", 2),
+           "self_attn.out_proj": ("o", None), "mlp.fc1": ("fc1", None), "mlp.fc2": ("fc2", None)}
+
+
+def parse_te_lora(raw: dict, n_layers: int, index: int) -> tuple[dict, list]:
+    """Entries of ``raw`` that target text encoder ``index`` (0: CLIP-L / the only one, 1: SDXL's second) ->
+    ({(layer, sub-module): (down, up, alpha)}, matched keys)."""
+    kohya = ["lora_te_", "lora_te1_"] if index == 0 else ["lora_te2_"]
+    peft = ["text_encoder."] if index == 0 else ["text_encoder_2."]
+    names = {}
+    for i in range(n_layers):
+        for sub in _TE_SUB:
+            path = f"text_model.encoder.layers.{i}.{sub}"
+            for pre in kohya:
+                names[pre + path.replace(".", "_")] = (i, sub)
+            for pre in peft:
+                names[pre + path] = (i, sub)
+    alphas = {k[:-6]: float(v) for k, v in raw.items() if k.endswith(".alpha")}
+    found, used = {}, []
+    for k, v in raw.items():
+        m = re.match(r"^(.*?)\.(lora_down|lora_up|lora_A|lora_B|lora_linear_layer\.down|lora_linear_layer\.up)\.weight$", k)
+        if not m or m.group(1) not in names:
+            continue
+        used.append(k)
+        e = found.setdefault(names[m.group(1)], {"alpha": alphas.get(m.group(1))})
+        e["down" if m.group(2) in ("lora_down", "lora_A", "lora_linear_layer.down") else "up"] = v.float().reshape(v.shape[0], -1)
+    out = {key: (e["down"], e["up"], e["alpha"] if e["alpha"] is not None else float(e["down"].shape[0]))
+           for key, e in found.items() if "down" in e and "up" in e}
+    return out, used
+
+
+class ClipLora:
+    """Deltas of one LoRA for one native CLIP text encoder (clip.ClipTextHip); same in-place axpy merge as LoraStyle."""
+
+    def __init__(self, enc, raw: dict, index: int = 0):
+        parsed, self.used = parse_te_lora(raw, enc.L, index)
+        self.enc = enc
+        self.modules = sorted(parsed)
+        deltas = {}
+        for (layer, sub), (down, up, alpha) in parsed.items():
+            d = (up @ down) * (alpha / down.shape[0])
+            tgt, part = _TE_SUB[sub]
+            name = f"{layer}.{tgt}.w"
+            w = enc.w[name]
+            t = deltas.setdefault(name, torch.zeros(w.shape, dtype=torch.float32))
+            if part is None:
+                t += d
+            else:
+                t[part * enc.D:(part + 1) * enc.D] += d
+        self.delta = {n: t.to(torch.float16).to(enc.device).contiguous() for n, t in deltas.items()}
+        self.base = {n: enc.w[n].clone() for n in self.delta}
+        self.current = 0.0
+
+    def nbytes(self):
+        return 2 * sum(t.numel() * 2 for t in self.delta.values())
+
+    def apply(self, weight: float):
+        weight = float(weight)
+        if weight == self.current:
+            return
+        for n, d in self.delta.items():
+            ops.axpy(self.base[n], d, weight, self.enc.w[n])
+        self.current = weight
+
+
+class StyleAdapters:
+    """Everything one style file touches: the UNet deltas plus one ClipLora per text encoder that has entries."""
+
+    def __init__(self, unet, encoders, raw: dict):
+        self.unet = LoraStyle(unet, raw)
+        self.text = [c for c in (ClipLora(e, raw, i) for i, e in enumerate(encoders)) if c.modules]
+        te_keys = {k for c in self.text for k in c.used}
+        self.modules = self.unet.modules
+        self.skipped = [k for k in self.unet.skipped if k not in te_keys]
+        self.text_modules = sum(len(c.modules) for c in self.text)
+
+    def nbytes(self):
+        return self.unet.nbytes() + sum(c.nbytes() for c in self.text)
+
+    def apply(self, weight: float):
+        self.unet.apply(weight)
+        for c in self.text:
+            c.apply(weight)

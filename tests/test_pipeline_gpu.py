@@ -330,6 +330,53 @@ def test_sdxl_style_pipeline_parity(guidance):
     hip.drop_plans()
 
 
+def test_text_encoder_lora_merge_parity_and_restore():
+    """Text-encoder LoRA entries of a style file (kohya ``lora_te_`` / ``lora_te2_`` and peft ``text_encoder.`` keys; q/k/v
+    rows of the fused projection, out_proj, fc1, fc2) merged in place into the native CLIP encoder: output must match
+    transformers' CLIP on explicitly merged weights, weight 0 must restore the base output bit for bit."""
+    from sdlcm_amd.clip import CLIP_L, ClipTextHip, HashTokenizer, synthetic_clip
+    from sdlcm_amd.lora import ClipLora, parse_te_lora
+    from oracle.clip import clip_text_oracle
+    cfg = dict(CLIP_L, num_hidden_layers=3)
+    sd = synthetic_clip(cfg, seed=7)
+    g = torch.Generator().manual_seed(41)
+    targets = [(0, "self_attn.q_proj", "kohya"), (0, "self_attn.v_proj", "peft"), (1, "self_attn.out_proj", "kohya"),
+               (1, "mlp.fc1", "peft"), (2, "mlp.fc2", "kohya"), (2, "self_attn.k_proj", "kohya")]
+    raw, merged, r, alpha, wt = {}, dict(sd), 4, 2.0, 0.8
+    for layer, sub, style in targets:
+        name = f"encoder.layers.{layer}.{sub}.weight"
+        W = sd[name]
+        down = torch.randn(r, W.shape[1], generator=g) * (W.shape[1] ** -0.5)
+        up = torch.randn(W.shape[0], r, generator=g) * 0.3
+        path = f"text_model.encoder.layers.{layer}.{sub}"
+        if style == "kohya":
+            k = "lora_te_" + path.replace(".", "_")
+            raw[k + ".lora_down.weight"], raw[k + ".lora_up.weight"], raw[k + ".alpha"] = down, up, torch.tensor(alpha)
+            scale = alpha / r
+        else:
+            k = "text_encoder." + path
+            raw[k + ".lora_A.weight"], raw[k + ".lora_B.weight"] = down, up
+            scale = 1.0
+        merged[name] = (W.float() + wt * ((up @ down) * scale).to(torch.float16).float()).to(torch.float16)
+    raw["lora_te2_text_model_encoder_layers_0_mlp_fc1.lora_down.weight"] = torch.zeros(r, 8)      # second encoder: not ours
+    raw["lora_unet_mid_block_attentions_0_proj_in.lora_down.weight"] = torch.zeros(r, 8)
+    parsed, used = parse_te_lora(raw, 3, 0)
+    assert len(parsed) == len(targets) and all("te2" not in k and "unet" not in k for k in used)
+    ids = HashTokenizer()(["a papercut illustration of a fox", ""])
+    enc = ClipTextHip(sd, cfg, device="cuda:0")
+    base = enc.forward(ids).clone()
+    lora = ClipLora(enc, raw, 0)
+    assert len(lora.modules) == len(targets)
+    lora.apply(wt)
+    got = enc.forward(ids).float().cpu().numpy()
+    ref = clip_text_oracle(merged, cfg, ids).numpy()
+    e = _report("clip with text-encoder LoRA", got, ref)
+    assert e.max() < 2e-2 * max(1.0, np.abs(ref).max())
+    assert np.abs(got - base.float().cpu().numpy()).max() > 1e-2         # the merge really changed the encoder
+    lora.apply(0.0)
+    assert torch.equal(enc.forward(ids), base)
+
+
 def test_lora_style_merge_parity_and_restore(state):
     """A synthetic LoRA over every supported target kind (fused q|k|v rows, stacked cross-attention K/V, GEGLU
     interleave, proj_in/out, out-projections, ff.net.2): the in-place merge W + weight * (BA) alpha/r must match the
