@@ -9,7 +9,10 @@ Supported targets: every Linear / 1x1-conv of the transformer blocks (proj_in/ou
 key styles: kohya (``lora_unet_<path>.lora_down.weight`` / ``.lora_up.weight`` / ``.alpha``) and peft / diffusers
 (``unet.<path>.lora_A.weight`` / ``.lora_B.weight``).  Text-encoder entries (``lora_te_`` / ``lora_te1_`` / ``lora_te2_`` /
 ``text_encoder[_2].``: the q/k/v/out projections and the MLP of every CLIP layer) are merged into the native CLIP
-encoders the same way (``ClipLora``), as ``pipe.load_lora_weights`` does for the reference.  Conv (LoCon) entries are
+encoders the same way (``ClipLora``), as ``pipe.load_lora_weights`` does for the reference.  LoCon entries on the
+ResnetBlock2D convolutions (conv1 / conv2 3x3: down [r,Cin,3,3] x up [Cout,r,1,1]; conv_shortcut 1x1), the resnets'
+time_emb_proj, and the down/upsampler convolutions are merged too, each delta packed the way its weight is (tap-major
+3x3 rows, the four-phase upsampler layout, the stacked time-embedding matrix).  conv_in / conv_out entries are
 reported and skipped.
 """
 from __future__ import annotations
@@ -19,16 +22,21 @@ import re
 import torch
 
 from . import ops
-from .packing import pack_geglu
+from .packing import pack_conv1x1, pack_conv3x3, pack_conv3x3_up2, pack_geglu
 from .weights import unet_param_spec
+
+
+_CONV_TARGET = re.compile(r"\.resnets\.\d+\.(conv1|conv2|conv_shortcut|time_emb_proj)$|\.(downsamplers|upsamplers)\.0\.conv$")
 
 
 def _target_modules(cfg):
     out = {}
     for name, shape, kind in unet_param_spec(cfg):
-        if not name.endswith(".weight") or ".attentions." not in name or kind not in ("w", "w_res"):
+        if not name.endswith(".weight"):
             continue
-        out[name[:-7]] = tuple(shape)
+        mod = name[:-7]
+        if (".attentions." in name and kind in ("w", "w_res")) or _CONV_TARGET.search(mod):
+            out[mod] = tuple(shape)
     return out
 
 
@@ -55,7 +63,8 @@ def parse_lora(raw: dict, cfg) -> tuple[dict, list]:
             skipped.append(k)
             continue
         e = found.setdefault(mod, {"alpha": alphas.get(stem)})
-        e["down" if part in ("lora_down", "lora_A") else "up"] = v.float().reshape(v.shape[0], -1)
+        # LoCon keeps the 3x3 extent on lora_down ([r, Cin, 3, 3]); lora_up is [Cout, r(,1,1)]
+        e["down" if part in ("lora_down", "lora_A") else "up"] = v.float() if (v.dim() == 4 and v.shape[-1] > 1) else v.float().reshape(v.shape[0], -1)
     out = {}
     for mod, e in found.items():
         if "down" in e and "up" in e:
@@ -82,6 +91,9 @@ class LoraStyle:
             t[rows[0]:rows[1]] += d
 
         for mod, (down, up, alpha) in parsed.items():
+            if _CONV_TARGET.search(mod):
+                self._conv_delta(unet, mod, down, up, alpha, acc)
+                continue
             d = (up @ down) * (alpha / down.shape[0])                        # [out, in]
             m = re.match(r"^(.*\.attentions\.\d+)\.(.*)$", mod)
             p, rest = m.group(1), m.group(2)
@@ -112,6 +124,30 @@ class LoraStyle:
         self.delta = {n: t.to(torch.float16).to(dev).contiguous() for n, t in deltas.items()}
         self.base = {n: unet.w[n].clone() for n in self.delta}
         self.current = 0.0
+
+    @staticmethod
+    def _conv_delta(unet, mod, down, up, alpha, acc):
+        """LoCon / linear entries outside the transformer blocks, packed like the weight they modify (model.UNetHip)."""
+        from .model import UPS_PHASES
+        r = down.shape[0]
+        scale = alpha / r
+        if mod.endswith(".time_emb_proj"):
+            off, n = unet.temb_off[mod[:-len(".time_emb_proj")]]
+            acc("temb_all.w", (off, off + n), (up @ down.reshape(r, -1)) * scale)
+            return
+        if down.dim() == 4:                       # 3x3 LoCon: delta[o,i,ky,kx] = sum_r up[o,r] down[r,i,ky,kx]
+            d4 = torch.einsum("or,rikl->oikl", up.reshape(up.shape[0], r), down) * scale
+        else:                                      # 1x1 (conv_shortcut) or a 3x3 target given as a plain matrix
+            d2 = (up.reshape(up.shape[0], r) @ down) * scale
+            d4 = d2.reshape(d2.shape[0], -1, 1, 1)
+        if mod.endswith(".conv_shortcut"):
+            acc(mod.replace(".conv_shortcut", ".sc") + ".w", (0, d4.shape[0]), pack_conv1x1(d4))
+            return
+        if d4.shape[-1] != 3:
+            raise ValueError(f"LoRA entry for {mod}: expected a 3x3 LoCon pair, got down {tuple(down.shape)}")
+        name = mod + ".w"
+        packed = pack_conv3x3_up2(d4) if (".upsamplers." in mod and UPS_PHASES) else pack_conv3x3(d4)
+        acc(name, (0, packed.shape[0]), packed)
 
     def nbytes(self):
         return 2 * sum(t.numel() * 2 for t in self.delta.values())

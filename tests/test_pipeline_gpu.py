@@ -395,6 +395,23 @@ def test_lora_style_merge_parity_and_restore(state):
                "up_blocks.3.attentions.2.proj_out"]
     raw, r, alpha, wt = {}, 8, 4.0, 0.9
     merged = dict(usd)
+    # LoCon entries: 3x3 resnet convs, the 1x1 shortcut, time_emb_proj, a stride-2 downsampler and a (phase-packed) upsampler
+    conv_targets = ["down_blocks.0.resnets.1.conv1", "up_blocks.1.resnets.0.conv2", "up_blocks.2.resnets.0.conv_shortcut",
+                    "mid_block.resnets.0.time_emb_proj", "down_blocks.1.downsamplers.0.conv", "up_blocks.1.upsamplers.0.conv"]
+    for m in conv_targets:
+        W = usd[m + ".weight"]
+        key = "lora_unet_" + m.replace(".", "_")
+        if W.dim() == 4:
+            kk = W.shape[-1]
+            down = torch.randn(r, W.shape[1], kk, kk, generator=g) * ((W.shape[1] * kk * kk) ** -0.5)
+            up = torch.randn(W.shape[0], r, 1, 1, generator=g) * 0.5
+            delta = torch.einsum("or,rikl->oikl", up.reshape(W.shape[0], r), down) * (alpha / r)
+        else:
+            down = torch.randn(r, W.shape[1], generator=g) * (W.shape[1] ** -0.5)
+            up = torch.randn(W.shape[0], r, generator=g) * 0.5
+            delta = (up @ down) * (alpha / r)
+        raw[key + ".lora_down.weight"], raw[key + ".lora_up.weight"], raw[key + ".alpha"] = down, up, torch.tensor(alpha)
+        merged[m + ".weight"] = (W.float() + wt * delta.to(torch.float16).float()).to(torch.float16)
     for i, m in enumerate(targets):
         W = usd[m + ".weight"]
         out_f, in_f = W.shape[0], W.reshape(W.shape[0], -1).shape[1]
@@ -413,7 +430,7 @@ def test_lora_style_merge_parity_and_restore(state):
     base = hip.generate(pe, [4], 128, 128, 2, 1.0, want_float=True)
     with torch.cuda.stream(hip.stream):
         style = LoraStyle(hip.unet, raw)
-        assert len(style.modules) == len(targets) and not style.skipped
+        assert len(style.modules) == len(targets) + len(conv_targets) and not style.skipped
         style.apply(wt)
     try:
         out = hip.generate(pe, [4], 128, 128, 2, 1.0, want_float=True)
