@@ -84,6 +84,10 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise LcmHipError(f"{LIB_PATH} not built: run __graft_entry__.build() (make -C csrc); "
                           "there is no CPU fallback for the HIP path")
+    # liblcmhip.so needs libamdhip64.so.7; PyTorch-ROCm bundles its own copy.  Whichever is mapped first serves BOTH, so
+    # torch must come first: with the system runtime loaded ahead of torch's, device memory, streams and the kernels end
+    # up on mismatched runtimes ("set_workspace: no device" when build() and smoke() ran in one process).
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, sig in _SIGS.items():
         fn = getattr(lib, name)
