@@ -85,8 +85,8 @@ def roofline_leg(pipe, P, guidance, ms_per_step):
     assert len(recs) == len(times) == len(closures), (len(recs), len(times), len(closures))
     agg = {}
     for r, (name, ms), c in zip(recs, times, closures):
-        a = agg.setdefault(name, dict(n=0, flops=0.0, ms=0.0, kind=r["kind"], fns=[]))
-        a["n"] += 1; a["flops"] += r["flops"]; a["ms"] += ms; a["fns"].append(c[2])
+        a = agg.setdefault(name, dict(n=0, flops=0.0, bytes=0.0, ms=0.0, kind=r["kind"], fns=[]))
+        a["n"] += 1; a["flops"] += r["flops"]; a["bytes"] += r.get("bytes", 0.0); a["ms"] += ms; a["fns"].append(c[2])
     name, dom = max(agg.items(), key=lambda kv: kv[1]["ms"])
     with torch.cuda.stream(pipe.stream):
         for fn in dom["fns"]:
@@ -105,12 +105,38 @@ def roofline_leg(pipe, P, guidance, ms_per_step):
     table = {k: {"launches": v["n"], "bracketed_ms": round(v["ms"], 3), "bracketed_avg_us": round(v["ms"] * 1e3 / v["n"], 2),
                  "gflop": round(v["flops"] / 1e9, 1)} for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
     tot_f = sum(v["flops"] for v in agg.values())
-    return {"bound": "mfma", "kernel": f"{name} ({dom['kind']})",
+    traffic, traffic_src = _pmc_traffic(name, P.B)
+    out = {"bound": "mfma", "kernel": f"{name} ({dom['kind']})",
             "achieved": round(ach, 1), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_F16_PEAK_TFLOPS, 4),
             "launches": dom["n"], "avg_launch_us": round(iso_ms * 1e3 / dom["n"], 2),
-            "flop_per_launch_avg": round(dom["flops"] / dom["n"]), "traffic": None,
+            "flop_per_launch_avg": round(dom["flops"] / dom["n"]), "traffic": traffic,
             "method": "dominant instantiation replayed back-to-back on its real per-layer operands inside one HIP event pair",
             "mfma_flop_per_pass": round(tot_f), "by_kernel": table}
+    if traffic is not None:
+        out["algorithmic_bytes_per_launch_avg"] = round(dom["bytes"] / dom["n"])     # operands + result, each counted once
+        out["traffic_unit"] = "bytes per launch (fabric reads + writes)"
+        out["traffic_source"] = traffic_src
+    return out
+
+
+def _pmc_traffic(kernel_name, batch):
+    """HBM-side bytes per launch of `kernel_name`, from the committed PMC passes (profiles/r01_traffic.json: rocprofv3 --pmc
+    FETCH_SIZE and WRITE_SIZE in separate runs over one eager pass of this workload, tools/pmc_pass.sh; counters cannot be
+    read from inside bench.py).  FETCH_SIZE x2 is the gfx950 correction of MI355X_MICROARCH.md's HBM section.  None when
+    the kernel / batch was not profiled -- never a guess."""
+    import json
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")
+    try:
+        with open(path) as f:
+            tab = json.load(f)["batch"].get(str(batch), {})
+    except Exception:
+        return None, None
+    e = tab.get(kernel_name)
+    if not e:
+        return None, None
+    return int((2.0 * e["FETCH_SIZE"] + e["WRITE_SIZE"]) * 1024), (
+        f"profiles/r01_traffic.json: FETCH_SIZE {e['FETCH_SIZE']:.0f} KB x2 (gfx950 correction) + WRITE_SIZE {e['WRITE_SIZE']:.0f} KB, "
+        f"averaged over {e['n_FETCH_SIZE']} launches of this kernel in an eager pass (separate --pmc runs)")
 
 
 def main():
