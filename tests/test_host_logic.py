@@ -292,3 +292,19 @@ def test_plan_table_sources_and_gn_fusion_rule(tmp_path, monkeypatch):
     assert model._fuse_gn_into_conv(512 * 512, 128, 128)                # ... and at batch 1 (67 MB)
     assert not model._fuse_gn_into_conv(4096, 320, 320)                 # batch-1 UNet level: 2.6 MB, served from cache
     assert not model._fuse_gn_into_conv(8 * 128 * 128, 512, 512)        # 4 n-tiles of 128: the transform would repeat 4x
+
+
+def test_bench_traffic_lookup_reads_committed_pmc_table():
+    """bench.py's roofline.traffic comes from profiles/r01_traffic.json (separate --pmc passes): 2 x FETCH_SIZE + WRITE_SIZE
+    in bytes for a profiled (kernel, batch), None -- never a guess -- for anything else."""
+    import importlib.util, json, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    tab = json.load(open(os.path.join(root, "profiles", "r01_traffic.json")))["batch"]
+    name, e = next(iter(tab["1"].items()))
+    t, src = bench._pmc_traffic(name, 1)
+    assert t == int((2 * e["FETCH_SIZE"] + e["WRITE_SIZE"]) * 1024) and "x2" in src
+    assert bench._pmc_traffic("no_such_kernel<1>", 1) == (None, None)
+    assert bench._pmc_traffic(name, 3) == (None, None)
