@@ -33,32 +33,28 @@ def host_threads():
 
 
 def cpu_baseline(threads):
-    """Oracle (CPU restatement, kind 'port') on a bounded sample of the same workload:
-    one UNet forward + one VAE decode at 512x512 (latent 64x64); image time = 4*unet + vae."""
+    """Oracle (CPU restatement, kind 'port') on a bounded sample of the same workload: ONE whole 512x512 4-step image
+    through LCMPipelineOracle (latents from the seed -> 4 x [UNet -> LCMScheduler.step] -> VAE decode -> u8), after one
+    warm-up UNet forward (thread pool, allocator)."""
     import numpy as np
     import torch
     from sdlcm_amd import weights
-    from oracle.unet import UNetOracle
-    from oracle.vae import VAEDecoderOracle
+    from oracle.pipeline import LCMPipelineOracle
     from oracle import glue
     torch.set_num_threads(threads)
-    unet = UNetOracle(weights.synthetic_unet())
-    vae = VAEDecoderOracle(weights.synthetic_vae())
+    ora = LCMPipelineOracle(weights.synthetic_unet(), weights.synthetic_vae())
     g = torch.Generator().manual_seed(0)
-    lat = torch.randn(1, 4, 64, 64, generator=g)
     pe = torch.randn(1, 77, 768, generator=g)
     cond = torch.from_numpy(glue.guidance_scale_embedding(np.zeros(1, np.float32), 256))
-    unet.forward(lat, 999, pe, cond)                                   # warm-up (thread pool, allocator)
-    tu, tv = [], []
-    for t in (999, 759, 499):
-        t0 = time.time(); unet.forward(lat, t, pe, cond); tu.append(time.time() - t0)
-    for _ in range(2):
-        t0 = time.time(); vae.decode(lat); tv.append(time.time() - t0)
-    t_unet, t_vae = sorted(tu)[1], min(tv)
-    t_img = 4 * t_unet + t_vae
+    with torch.inference_mode():
+        ora.unet.forward(torch.randn(1, 4, 64, 64, generator=g), 999, pe, cond)          # warm-up
+    t0 = time.time()
+    out = ora(pe, 512, 512, 4, 1.0, 1000)
+    t_img = time.time() - t0
+    assert out["image_u8"].size == 512 * 512 * 3
     return {"value": round(1.0 / t_img, 5), "unit": "images/s", "cores": threads, "kind": "port",
-            "sample": f"3 UNet forwards (median {t_unet:.2f}s) + 2 VAE decodes (best {t_vae:.2f}s) at 512x512, "
-                      f"torch-CPU fp32 oracle, {threads} threads; image = 4*unet + vae = {t_img:.1f}s"}
+            "sample": f"1 whole 512x512 4-step image (seed 1000) through oracle.pipeline.LCMPipelineOracle after one warm-up "
+                      f"UNet forward: {t_img:.2f} s, torch-CPU fp32, {threads} threads"}
 
 
 def roofline_leg(pipe, P, guidance, ms_per_step):
@@ -112,31 +108,58 @@ def roofline_leg(pipe, P, guidance, ms_per_step):
             "flop_per_launch_avg": round(dom["flops"] / dom["n"]), "traffic": traffic,
             "method": "dominant instantiation replayed back-to-back on its real per-layer operands inside one HIP event pair",
             "mfma_flop_per_pass": round(tot_f), "by_kernel": table}
-    if traffic is not None:
-        out["algorithmic_bytes_per_launch_avg"] = round(dom["bytes"] / dom["n"])     # operands + result, each counted once
-        out["traffic_unit"] = "bytes per launch (fabric reads + writes)"
-        out["traffic_source"] = traffic_src
+    out["algorithmic_bytes_per_launch_avg"] = round(dom["bytes"] / dom["n"])     # operands + result, each counted once
+    out["traffic_unit"] = "bytes per launch (fabric reads + writes)"
+    out["traffic_source"] = traffic_src
+    out["kernel_launches_per_pass"] = len(times)
     return out
 
 
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
+
+
 def _pmc_traffic(kernel_name, batch):
-    """HBM-side bytes per launch of `kernel_name`, from the committed PMC passes (profiles/r01_traffic.json: rocprofv3 --pmc
+    """HBM-side bytes per launch of `kernel_name`, from the committed PMC passes (profiles/r02_traffic.json: rocprofv3 --pmc
     FETCH_SIZE and WRITE_SIZE in separate runs over one eager pass of this workload, tools/pmc_pass.sh; counters cannot be
-    read from inside bench.py).  FETCH_SIZE x2 is the gfx950 correction of MI355X_MICROARCH.md's HBM section.  None when
-    the kernel / batch was not profiled -- never a guess."""
+    read from inside bench.py).  FETCH_SIZE x2 is the gfx950 correction of MI355X_MICROARCH.md's HBM section.  When the
+    dominant kernel / batch is not in the file the value is None AND the reason is reported (`traffic_source`) and printed
+    to stderr -- never a silent null, never a guess."""
     import json
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")
     try:
-        with open(path) as f:
+        with open(TRAFFIC_FILE) as f:
             tab = json.load(f)["batch"].get(str(batch), {})
-    except Exception:
-        return None, None
+    except Exception as e:
+        msg = f"{os.path.relpath(TRAFFIC_FILE, ROOT)} unreadable ({e!r}): traffic not reported"
+        print("[bench] WARNING: " + msg, file=sys.stderr)
+        return None, msg
     e = tab.get(kernel_name)
     if not e:
-        return None, None
+        msg = (f"dominant kernel '{kernel_name}' (batch {batch}) is absent from {os.path.relpath(TRAFFIC_FILE, ROOT)} "
+               f"(has: {sorted(tab)[:6]}...): re-run tools/pmc_pass.sh")
+        print("[bench] WARNING: " + msg, file=sys.stderr)
+        return None, msg
     return int((2.0 * e["FETCH_SIZE"] + e["WRITE_SIZE"]) * 1024), (
-        f"profiles/r01_traffic.json: FETCH_SIZE {e['FETCH_SIZE']:.0f} KB x2 (gfx950 correction) + WRITE_SIZE {e['WRITE_SIZE']:.0f} KB, "
-        f"averaged over {e['n_FETCH_SIZE']} launches of this kernel in an eager pass (separate --pmc runs)")
+        f"{os.path.relpath(TRAFFIC_FILE, ROOT)}: FETCH_SIZE {e['FETCH_SIZE']:.0f} KB x2 (gfx950 correction) + WRITE_SIZE "
+        f"{e['WRITE_SIZE']:.0f} KB, averaged over {e['n_FETCH_SIZE']} launches of this kernel in an eager pass (separate --pmc runs)")
+
+
+def spawn_command(gpus, argv, env):
+    """`python bench.py --gpus N` run by hand (no torchrun environment): the command that launches N fresh ranks, one per
+    GPU.  None when this process already IS a rank (RANK / WORLD_SIZE set by torch.distributed.run) or N == 1.  A
+    WORLD_SIZE that disagrees with --gpus is an error, not something to paper over."""
+    ws = env.get("WORLD_SIZE")
+    if ws is not None:
+        if int(ws) != int(gpus):
+            raise SystemExit(f"bench.py: --gpus {gpus} but WORLD_SIZE={ws}: launch with --nproc-per-node {gpus}")
+        return None
+    if int(gpus) <= 1:
+        return None
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(gpus)}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
 
 
 def main():
@@ -153,6 +176,15 @@ def main():
     ap.add_argument("--no-extra", action="store_true")
     args = ap.parse_args()
 
+    # N > 1 without a torchrun environment: become the launcher.  The parent never touches the GPU (no torch import, no
+    # library call before this point); every rank is a fresh child process.
+    cmd = spawn_command(args.gpus, sys.argv[1:], os.environ)
+    if cmd is not None:
+        import subprocess
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
     import numpy as np
     import torch
     import sdlcm_amd  # noqa: F401
@@ -165,8 +197,9 @@ def main():
     dist = None
     # rehearsal only (one-GPU box): LCM_BENCH_BACKEND=gloo LCM_BENCH_ONE_DEVICE=1 runs N ranks on cuda:0 with CPU
     # collectives, exercising everything of the N>1 path except RCCL itself
-    backend = os.environ.get("LCM_BENCH_BACKEND", "nccl")
-    if os.environ.get("LCM_BENCH_ONE_DEVICE", "0") == "1":
+    one_dev = os.environ.get("LCM_BENCH_ONE_DEVICE", "0") == "1"
+    backend = os.environ.get("LCM_BENCH_BACKEND", "gloo" if one_dev else "nccl")      # RCCL refuses two ranks on one device
+    if one_dev:
         local = 0
     if world > 1:
         import torch.distributed as dist
@@ -190,6 +223,8 @@ def main():
     h = w = S // 8
     D = pipe.unet.ctx_dim
 
+    bcast_ms = {}
+
     def prime(Bx):
         """Fill a plan's resident inputs: embeddings broadcast from rank 0 over RCCL, per-request noise."""
         P = pipe.plan(Bx, h, w, n)
@@ -199,13 +234,18 @@ def main():
                 allpe.copy_(torch.randn(world * Bx, 77, D, generator=torch.Generator().manual_seed(1)).half())
             if dist is not None:
                 pipe.stream.synchronize()
-                if backend == "nccl":
-                    dist.broadcast(allpe, src=0)      # the one exchange step: 118 KB per prompt over xGMI
-                else:
-                    host = allpe.cpu()
-                    dist.broadcast(host, src=0)
-                    allpe.copy_(host)
-                torch.cuda.synchronize()
+                for rep in range(2):                  # first call sets the communicator up; the second is the exchange itself
+                    dist.barrier()
+                    torch.cuda.synchronize()
+                    tb = time.perf_counter()
+                    if backend == "nccl":
+                        dist.broadcast(allpe, src=0)      # the one exchange step: 118 KB per prompt over xGMI
+                    else:
+                        host = allpe.cpu()
+                        dist.broadcast(host, src=0)
+                        allpe.copy_(host)
+                    torch.cuda.synchronize()
+                    bcast_ms[Bx] = (time.perf_counter() - tb) * 1e3
             P.ehs.copy_(allpe[rank * Bx:(rank + 1) * Bx].reshape(Bx * 77, D))
             if pipe.unet.has_added:      # SDXL: pooled text embedding + size/crop ids
                 from sdlcm_amd.pipeline import sinusoid_host
@@ -252,8 +292,12 @@ def main():
 
     P = prime(B)
     dt, p50 = timed(P, args.steps, args.warmup)
+    per_rank = [round(B * args.steps / dt, 3)]
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        per_rank = [round(B * args.steps / float(x.item()), 3) for x in allt]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     images = world * B * args.steps
@@ -261,13 +305,16 @@ def main():
         "metric": f"{S}x{S} {n}-step LCM images/sec", "value": round(images / dt, 3), "unit": "images/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-        "p50_latency_ms": round(p50, 3),
+        "p50_latency_ms": round(p50, 3), "per_rank_images_per_s": per_rank,
         "config": {"workload": f"{'SDXL-base' if args.model == 'sdxl' else 'SD1.5'} LCM {S}x{S}, {n} steps, guidance 1.0 (no CFG), "
                                f"batch {B} per GPU, fp16 (fp32 accumulate), hipGraph replay; seeded synthetic "
                                f"{'SDXL' if args.model == 'sdxl' else 'SD1.5'}-architecture weights",
                    "batch_per_gpu": B, "global_batch": world * B, "image": f"{S}x{S}", "lcm_steps": n,
                    "parallelism": f"independent requests x{world} (RCCL broadcast of prompt embeddings only)"},
     }
+    if world > 1:
+        line["exchange"] = {"what": f"broadcast of [{world * B},77,{D}] fp16 prompt embeddings from rank 0, before the timed region",
+                            "backend": "rccl" if backend == "nccl" else backend, "ms": round(bcast_ms.get(B, 0.0), 3)}
     if rank == 0 and world == 1:
         line["roofline"] = roofline_leg(pipe, P, 1.0, dt / args.steps * 1e3)
         if args.model == "sdxl":

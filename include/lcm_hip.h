@@ -47,31 +47,48 @@ int lcm_gemm_f16(const void* A, int lda, const void* A2, int lda2, int K1,
                  const void* W, const void* bias, const void* rowadd, int ld_rowadd, int rows_per_batch,
                  const void* res, int ldr, void* out, int ldo,
                  int M, int N, int K, int epilogue, float out_scale,
-                 int batch, int64_t strideA, int64_t strideW, int64_t strideO,
-                 void* stats_out, int stats_hw, int* slabs_per_image, void* stream);
-/* Fused GroupNorm statistics (all three contraction entry points): stats_out != NULL asks the epilogue to also
- * write, per half-tile (or split-K reduce slab), the per-channel (sum, sum of squares) of the fp16 values it
- * stores: fp32 [B * slabs_per_image][N][2].  stats_hw = output rows per image (gemm only; the convs know it).
- * *slabs_per_image returns how many slabs each image got; 0 means the launch could not produce them (tile would
- * straddle two images, GEGLU/batched launch, N > 2048): use lcm_groupnorm_f16 on the output instead.
- * Consumer: lcm_groupnorm_from_stats_f16.  Buffer size: 8 * N * (max(M / 16, 256) + 64) bytes always suffices
- * (>= 32-row slabs from the tile epilogues incl. padding patches; <= max(M/32, 256) slabs from a split-K reduce). */
+                 int batch, int64_t strideA, int64_t strideW, int64_t strideO, int img_rows,
+                 void* stats_out, int* slabs_per_image, void* stream);
+/* img_rows = output rows PER IMAGE when the M rows stack several independent requests (M % img_rows == 0; 0: M is
+ * one image).  It keys everything that decides the fp32 summation order (see "Determinism" below).
+ *
+ * Fused GroupNorm statistics (all three contraction entry points): stats_out != NULL asks the epilogue to also
+ * write the per-channel (sum, sum of squares) of the fp16 values it stores, per CANONICAL 32-pixel slab of the
+ * output (32 consecutive rows of a GEMM; a 2x16 -- 4x8 for images up to 16 wide -- pixel patch of a 3x3 convolution;
+ * a split-K reduce slab): fp32 [B * slabs_per_image][N][2].  Slabs are a property of the output tensor, never of
+ * the tile shape.  *slabs_per_image returns how many slabs each image got; 0 means the launch could not produce them
+ * (img_rows % 32 != 0, GEGLU/batched launch, N > 2048): use lcm_groupnorm_f16 on the output instead.
+ * Consumer: lcm_groupnorm_from_stats_f16.  Buffer size: 8 * N * (max(M / 16, 256) + 64) bytes always suffices. */
 
-/* Optional fp32 scratch for deterministic split-K (deep-K, small-M layers).  The caller owns the memory; it is
- * registered per current device and must outlive every later launch (graph replays included).  Without it the
- * contraction kernels never split.  bytes >= 4*splits*M*N of the layers that should split (32 MiB covers SD1.5). */
+/* fp32 scratch for deterministic split-K (deep-K, small-M layers).  The caller owns the memory; it is
+ * registered per current device and must outlive every later launch (graph replays included).  With no workspace
+ * registered the library never splits (a deployment either registers one, always, or never: the pipeline always
+ * does).  With one registered, a launch whose canonical K partition does not fit FAILS (LCM_EINVAL) -- it is never
+ * silently run with fewer parts, because that would change the numbers.  bytes >= 4*splits*M*N of the largest split
+ * layer (64 MiB covers SD1.5 at batch 1, 384 MiB batch 8). */
 int lcm_set_workspace(void* ptr, int64_t bytes);
 
 /* launch heuristics of the contraction kernels (0 keeps a value): workgroups a split-K launch aims for, the
- * maximum number of K splits, and the workgroup count below which a larger tile is passed over. */
+ * maximum number of K splits, and the workgroup count below which a larger tile is passed over.  These feed the
+ * canonical-partition heuristic: changing them changes fp32 summation order for shapes without a plan entry. */
 int lcm_set_tuning(int target_wgs, int max_splits, int min_wgs);
 
-/* Per-shape launch plans, normally written by the host-side autotuner (stable-diffusion-1.5-lcm-onnx-rknn2_amd/
- * autotune.py): kind 0 = lcm_gemm_f16 (aux = batch), 1 = row-gather conv (aux = 1), 2 = LDS-halo conv
- * (aux = (W_out << 1) | has_gn).  bm/bn in {64,128}; splits = K splits (needs the workspace); variant as below
- * (-1 = auto).  A plan only changes tile/split selection, never results beyond fp32 summation order. */
+/* Determinism.  The fp32 summation order of every output element is fixed by the K partition of its layer, and
+ * that partition is a function of the PER-IMAGE problem only: (kind, rows per image, N, K[, output width]) ->
+ * splits, from the plan entry of that per-image shape if one was set, else from a fixed heuristic.  Tile shape,
+ * pipeline depth and kernel variant (the plan entry of the TOTAL shape, or the occupancy heuristic) never change a
+ * bit of the result, and the fused statistics are slab-canonical.  Hence: same request + seed => same bytes, alone
+ * or inside a batch of any size, in any process, under any tuning of tile / variant (the reference contract
+ * tests/test_sdxl_worker.py:171-198, extended to micro-batches).
+ *
+ * Per-shape launch plans, normally loaded from the table shipped with the package (tuned offline): kind 0 =
+ * lcm_gemm_f16 (aux = batch), 1 = row-gather conv (aux = 1), 2 = LDS-halo conv (aux = (W_out << 1) | has_gn).
+ * bm in {64,128}, bn in {64,128,160}; variant as below (-1 = auto).  `splits` is honoured only through the entry
+ * whose M equals the rows per image of a launch (it then IS that shape's canonical partition). */
 int lcm_plan_set(int kind, int M, int N, int K, int aux, int bm, int bn, int splits, int variant);
 int lcm_plan_clear(void);
+/* the K partition a contraction of this per-image shape runs with (ph = 1: phase-decomposed upsample conv) */
+int lcm_canonical_splits(int kind, int m_img, int N, int K, int aux, int ph);
 
 /* 1: short-K GEMM launches with more tiles than the chip holds let each workgroup walk several n-tiles with a
  * continuous LDS-DMA pipeline (no ramp / drain per tile); 0 (default): one tile per workgroup.  Bit-identical. */

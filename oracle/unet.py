@@ -169,7 +169,14 @@ class UNetOracle:
                 if up_attn[i]:
                     x = self.transformer(f"up_blocks.{i}.attentions.{j}", x, ehs, nb - 1 - i)
             if i < nb - 1:
-                x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+                # UNet2DConditionModel.forward sets forward_upsample_size when the sample is not a multiple of
+                # 2**num_upsamplers and then hands every up block upsample_size = the next skip's spatial size;
+                # Upsample2D.forward: interpolate(size=output_size) in that case, interpolate(scale_factor=2) otherwise
+                tgt = tuple(skips[-1].shape[2:])
+                if tgt == (2 * x.shape[2], 2 * x.shape[3]):
+                    x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+                else:
+                    x = F.interpolate(x, size=tgt, mode="nearest")
                 x = self.conv(f"up_blocks.{i}.upsamplers.0.conv", x)
                 self._tap(f"up_blocks.{i}.upsamplers.0", x)
         x = F.silu(self.gn("conv_norm_out", x, cfg["norm_eps"]))

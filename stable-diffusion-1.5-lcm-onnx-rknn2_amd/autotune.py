@@ -1,10 +1,16 @@
 """Per-shape launch autotuner for the MFMA contraction kernels (gemm / conv3x3).
 
-The sampler touches ~80 distinct (M, N, K) contraction shapes per (batch, size) plan.  Tile shape, split-K
-factor and pipeline variant are pure launch parameters (results change only in fp32 summation order), and the
+The sampler touches ~80 distinct (M, N, K) contraction shapes per (batch, size) plan.  Tile shape and pipeline
+variant are pure launch parameters -- they never change a bit of the result (the K partition alone fixes the fp32
+summation order, and the fused statistics are slab-canonical: csrc/igemm.hip, "What decides the numbers") -- and the
 best choice depends on how many workgroups a shape yields on 256 CUs.  At plan-build time every distinct shape
-is replayed on its real buffers under each candidate configuration, timed with HIP events on the launch stream,
-and the winner is written to the library's plan table (``lcm_plan_set``).  ~0.5 s per plan, once.
+without an entry in the shipped table is replayed on its real buffers under each candidate configuration, timed with
+HIP events on the launch stream, and the winner is written to the library's plan table (``lcm_plan_set``).
+
+The split-K factor is NOT a launch parameter: it is the canonical partition of the per-image shape
+(``ops.canonical_splits``) and is only ever tuned offline (``tools/make_plans.py``, ``tune_splits=True``), into the
+table that ships with the package -- never by timing in a serving process, so results are reproducible across
+processes, boxes and batch sizes.
 
 Disable with LCM_AUTOTUNE=0 (the built-in heuristics of csrc/igemm.hip then apply).
 """
@@ -17,7 +23,13 @@ import torch
 from . import ops
 
 
-def _candidates(key, meta, ws_bytes, cold=False):
+def _canonical_splits(key, meta, M=None):
+    kind, M0, N, K, aux = key
+    ph = 1 if meta.get("phases", 1) == 4 else 0
+    return ops.canonical_splits(kind, M0 if M is None else M, N, K, aux if kind == 2 else 1, ph)
+
+
+def _candidates(key, meta, ws_bytes, cold=False, tune_splits=False):
     kind, M, N, K, aux = key
     nk = K // 64
     tiles = []
@@ -34,24 +46,24 @@ def _candidates(key, meta, ws_bytes, cold=False):
             elif bm == 128 and M < 128:
                 continue
             tiles.append((bm, bn))
+    # the plan entry's own split field is the canonical partition of a request whose rows-per-image equal this M
+    entry_splits = _canonical_splits(key, meta)
     out = []
     for bm, bn in tiles:
         ntile = -(-M // bm) * (N // bn) * (aux if kind == 0 else 1)
         taps = 4 if meta.get("phases", 1) == 4 else 9         # phase-decomposed upsample conv: K = 4 * Cin
         units = (K // (64 * taps)) if meta["halo"] else nk    # halo conv splits over 64-channel chunks
-        splits = [1]
-        if meta["splittable"]:
-            for s in (2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 24, 32):
+        splits = [entry_splits]
+        if tune_splits and meta.get("splittable") and meta.get("m_img", M) == M:      # offline, single-image shapes only
+            splits = [1]
+            for s in (2, 3, 4, 5, 6, 8, 10, 12, 16):
                 if s <= units and ntile * s <= 4096 and s * M * N * 4 <= ws_bytes and (meta["halo"] or s <= nk // 2):
                     splits.append(s)
         for s in splits:
-            # the pipeline depth is NOT tuned here: replaying one launch keeps its weights cache-resident, which
-            # hides exactly the latency the deeper variants exist for (in situ every weight byte comes from HBM);
-            # the library's occupancy rule picks it (csrc/igemm.hip launch_cfg)
-            # ... unless the timing itself runs cold (small-batch plans, see autotune(cold=True)): then the depth is a
-            # fair candidate for the GEMM kernels
-            # (GEMM: 0 = register-staged double buffer, LDS-DMA ring depth 1/2/4; halo conv: 1 = single-buffer, 2 = pipelined weight ring, 3 = pipelined with a
-            # whole kernel row of taps per K-step -- 64/128-wide tiles only)
+            # (GEMM: 0 = register-staged double buffer, LDS-DMA ring depth 1/2/4; halo conv: 1 = single-buffer, 2 =
+            # pipelined weight ring, 3 = pipelined with a whole kernel row of taps per K-step -- 64/128-wide tiles only).
+            # The depth is a fair candidate only when the timing runs cold (autotune(cold=True)): replaying one launch
+            # warm keeps its weights cache-resident, which hides exactly the latency the deeper variants exist for.
             variants = ((-1, 0, 1, 2, 4) if kind == 0 else ((1, 2, 3) if bn <= 128 else (1, 2)) if meta["halo"] else (-1,)) if cold else (-1,)
             for v in variants:
                 out.append((bm, bn, s, v))
@@ -103,29 +115,9 @@ def _cache_path():
     return os.environ.get("LCM_TUNE_CACHE", "")
 
 
-PACKAGED_PLANS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_plans_gfx950.json")
-
-
-def _read_plans(p):
-    import json
-    try:
-        with open(p) as f:
-            return {tuple(int(v) for v in k.split(",")): tuple(val) for k, val in json.load(f).items()}
-    except Exception:
-        return {}
-
-
 def _load_cache():
-    """Plans known before any tuning launch: the table shipped with the package (tools/make_plans.py: the standard
-    SD1.5 / SDXL request shapes, tuned on an MI355X with many cold repetitions -- launch parameters only, results are
-    unaffected) overlaid by the user's LCM_TUNE_CACHE file.  LCM_TUNED_PLANS=0 ignores the shipped table."""
-    cache = {}
-    if os.environ.get("LCM_TUNED_PLANS", "1") != "0" and os.path.exists(PACKAGED_PLANS):
-        cache.update(_read_plans(PACKAGED_PLANS))
-    p = _cache_path()
-    if p and os.path.exists(p):
-        cache.update(_read_plans(p))
-    return cache
+    from . import lib as _lib
+    return _lib.known_plans()
 
 
 def _save_cache(cache):
@@ -136,23 +128,27 @@ def _save_cache(cache):
             json.dump({",".join(str(v) for v in k): list(val) for k, val in cache.items()}, f)
 
 
-def autotune(records, ws_bytes, reps=None, verbose=False, cold=False):
+def autotune(records, ws_bytes, reps=None, verbose=False, cold=False, tune_splits=False):
     """records: list of (key, meta, replay) from ops.RECORD.  Returns {key: (bm, bn, splits, variant, ms)}.
-    LCM_TUNE_CACHE=<file> persists the winners (reproducible plans across processes, no tuning launches)."""
+    LCM_TUNE_CACHE=<file> persists the winners (no tuning launches next time).  tune_splits: offline table generation
+    only (tools/make_plans.py)."""
     reps = reps or int(os.environ.get("LCM_AUTOTUNE_REPS", "6"))
     seen, chosen = {}, {}
     cache = _load_cache()
     dirty = False
     for key, meta, fn in records:
         seen.setdefault(key, (meta, fn))
-    for key, (meta, fn) in seen.items():
+    # entries of the shipped / cached table first, single-image shapes before stacked ones: a stacked shape's K partition
+    # is read from the entry of its per-image shape
+    order = sorted(seen.items(), key=lambda kv: (kv[0] not in cache, kv[1][0].get("m_img", kv[0][1]) != kv[0][1]))
+    for key, (meta, fn) in order:
         if key in cache:
             bm, bn, s, v = (int(x) for x in cache[key][:4])
             ops.plan_set(key[0], key[1], key[2], key[3], key[4], bm, bn, s, v)
             chosen[key] = (bm, bn, s, v, float(cache[key][4]) if len(cache[key]) > 4 else 0.0)
             continue
         best = None
-        for (bm, bn, s, v) in _candidates(key, meta, ws_bytes, cold):
+        for (bm, bn, s, v) in _candidates(key, meta, ws_bytes, cold, tune_splits):
             ops.plan_set(key[0], key[1], key[2], key[3], key[4], bm, bn, s, v)
             if cold:
                 ms = _time_cold(fn, reps)

@@ -92,7 +92,8 @@ class MicroBatcher:
         with self._cv:
             self._closed = True
             self._cv.notify_all()
-        self._thread.join(timeout)
+        if threading.current_thread() is not self._thread:      # a finalizer may run on the dispatcher thread itself
+            self._thread.join(timeout)
         with self._cv:
             for e in self._q:
                 if not e[2].done():

@@ -17,6 +17,7 @@ import io
 import os
 import struct
 import threading
+import weakref
 import zlib
 from typing import Tuple
 
@@ -69,33 +70,105 @@ def encode_png(rgb) -> bytes:
 
 
 class _Engine:
-    """State shared by every worker the pool creates for one (family, device, checkpoint): the reference builds one
-    pipeline -- and one weight copy -- per ``worker_id`` (backends/worker_pool.py:60-71); here the workers of a GPU share
-    the resident weights, the captured graphs and one micro-batching dispatcher (backends/batching.py), so N pool
-    threads blocking in ``run_job`` become batched passes.  LCM_SHARE_ENGINE=0 restores one engine per worker."""
+    """Everything resident for one (family, device, checkpoint): the pipeline (weights, launch plans, captured graphs), the
+    text encoders, the style adapters and the micro-batching dispatcher.  The reference builds one pipeline -- and one
+    weight copy -- per ``worker_id`` (backends/worker_pool.py:60-71); here the workers the pool creates for a GPU share one
+    engine, so N pool threads blocking in ``run_job`` become batched passes.  LCM_SHARE_ENGINE=0: one engine per worker.
 
-    SHARED = ("pipe", "_encode", "_enc", "_tok", "_styles", "device", "dtype")
+    Lifetime: workers hold the engine, the engine never holds a worker, the registry and the dispatcher thread hold it
+    weakly.  The pool's teardown -- ``del worker; gc.collect(); torch.cuda.empty_cache()`` (backends/worker_pool.py:270-276),
+    no ``close()`` -- therefore releases the weights, plans, graphs and pinned buffers of the mode being unloaded."""
 
-    def __init__(self):
+    def __init__(self, family_cls):
+        self.family_cls = family_cls
         self.lock = threading.RLock()
         self.refs = 0
         self.batcher = None
         self.batch_sizes = (1,)
         self.active_style = None
-        self.first = None
+        self.pipe = None
+        self.encode = None           # SD1.5: HipPromptEncoder
+        self.enc, self.tok = [], []  # SDXL: two encoders / tokenizers
+        self.styles = {}
+        self.device = None
+        self.dtype = torch.float16
         self.timing = [] if os.environ.get("LCM_WORKER_TIMING", "0") == "1" else None
 
+    # ---- style LoRAs (backends/cuda_worker.py:123-196) -----------------------------------------
+    def apply_style(self, style_id, level):
+        """Exclusive style selection; level 0 / unknown style = off.  Re-merges only when the selection changes."""
+        from .styles import STYLE_REGISTRY
+        want = None
+        if style_id and int(level) > 0 and style_id in self.styles:
+            want = (style_id, STYLE_REGISTRY[style_id].weight_for(level))
+        if want == self.active_style:
+            return
+        with torch.cuda.stream(self.pipe.stream):
+            if self.active_style is not None and (want is None or want[0] != self.active_style[0]):
+                self.styles[self.active_style[0]].apply(0.0)
+            if want is not None:
+                self.styles[want[0]].apply(want[1])
+        self.active_style = want
+
+    def run_batch(self, key, items):
+        """One batched sampler pass for ``items`` = [(req, seed[, noise])], all of ``key``; -> per-item (rgb, pool8 row)."""
+        width, height, steps, g, style_id, level = key
+        import time as _t
+        t0 = _t.perf_counter()
+        with self.lock:                              # the pipeline, its plans and the merged weights are one resource
+            if self.pipe is None:
+                raise RuntimeError("worker engine is closed")
+            self.apply_style(style_id, level)        # lazy: no re-merge while consecutive batches use the same style
+            reqs = [it[0] for it in items]
+            with torch.cuda.stream(self.pipe.stream):
+                pe, kw = self.family_cls._conditioning(self, reqs, width, height, g)
+            t1 = _t.perf_counter()
+            noises = [it[2] for it in items] if all(len(it) > 2 and it[2] is not None for it in items) else None
+            out = self.pipe.generate(pe, [it[1] for it in items], width, height, steps, g, noises=noises, **kw)
+        t2 = _t.perf_counter()
+        if self.timing is not None:                  # LCM_WORKER_TIMING=1: (batch, conditioning s, sampler call s, end time)
+            self.timing.append((len(items), t1 - t0, t2 - t1, t2))
+        return [(out["rgb"][i], out["pool8"][i:i + 1]) for i in range(len(items))]
+
+    def start_batcher(self):
+        mb = int(os.environ.get("LCM_MICROBATCH", "8") or 0)
+        if mb <= 1:
+            return
+        from .batching import MicroBatcher
+        ref = weakref.ref(self)
+
+        def dispatch(key, items):                    # the dispatcher thread must not keep the engine alive
+            eng = ref()
+            if eng is None:
+                raise RuntimeError("worker engine is gone")
+            return eng.run_batch(key, items)
+        self.batcher = MicroBatcher(dispatch, max_batch=mb, window_ms=float(os.environ.get("LCM_MICROBATCH_WINDOW_MS", "0") or 0))
+        self.batch_sizes = tuple(self.batcher.sizes)
+        weakref.finalize(self, self.batcher.close)   # engine collected without close(): stop the dispatcher thread
+
     def release(self) -> bool:
+        """One worker less; the last one out shuts the engine down.  -> True when it did."""
         with _ENGINES_LOCK:
             self.refs -= 1
             if self.refs > 0:
                 return False
-            for k in [k for k, v in _ENGINES.items() if v is self]:
+            for k in [k for k, v in _ENGINES.items() if v() is self or v() is None]:
                 del _ENGINES[k]
-            return True
+        self.shutdown()
+        return True
+
+    def shutdown(self):
+        b, self.batcher = self.batcher, None
+        if b is not None:
+            b.close()
+        with self.lock:
+            pipe, self.pipe = self.pipe, None
+            if pipe is not None:
+                pipe.drop_plans()
+            self.encode, self.enc, self.tok, self.styles, self.active_style = None, [], [], {}, None
 
 
-_ENGINES: dict = {}
+_ENGINES: dict = {}              # key -> weakref.ref(_Engine)
 _ENGINES_LOCK = threading.Lock()
 
 
@@ -106,6 +179,7 @@ class HipLcmWorker:
 
     def __init__(self, worker_id: int):
         self.worker_id = worker_id
+        self._engine = None
         model_root = (os.environ.get("MODEL_ROOT") or "").strip()
         model_name = (os.environ.get("MODEL") or "").strip()
         synthetic = model_name.startswith("synthetic") or os.environ.get("LCM_HIP_SYNTHETIC", "0").lower() in ("1", "true", "yes", "on")
@@ -125,14 +199,14 @@ class HipLcmWorker:
         ekey = (self.FAMILY, device, "synthetic" if synthetic else os.path.join(model_root, model_name),
                 tuple(sorted((sid, sd.path()) for sid, sd in STYLE_REGISTRY.items())))
         with _ENGINES_LOCK:
-            eng = _ENGINES.get(ekey) if share else None
-            if eng is not None:
+            ref = _ENGINES.get(ekey) if share else None
+            eng = ref() if ref is not None else None
+            if eng is not None and eng.pipe is not None:
                 eng.refs += 1
+            else:
+                eng = None
         if eng is not None:                          # a sibling worker already holds this checkpoint on this GPU
             self._engine = eng
-            for k in _Engine.SHARED:
-                if k in eng.first.__dict__:
-                    setattr(self, k, eng.first.__dict__[k])
             print(f"[hip] worker {worker_id} ({self.FAMILY}) attached to the resident engine on {device} ({eng.refs} workers)")
             return
         sched = LCMSchedule()
@@ -162,33 +236,49 @@ class HipLcmWorker:
             # only the SDXL pipeline honours the VAE's force_upcast (StableDiffusionXLPipeline.upcast_vae); SD1.5 decodes in
             # the pipeline dtype whatever the checkpoint's vae/config.json says
             vcfg = dict(vcfg, force_upcast=False, residual_scale=1.0)
-        self.pipe = LcmHipPipeline(usd, vsd, ucfg, vcfg, device=device, schedule=sched)
-        with torch.cuda.stream(self.pipe.stream):
-            self._load_text_encoders(device, ckpt_root, clip_sd)
-        self.device = device
-        self.dtype = torch.float16
-        self._styles = {}
-        self._engine = eng = _Engine()
-        eng.refs, eng.first = 1, self
-        self._load_styles()
-        mb = int(os.environ.get("LCM_MICROBATCH", "8") or 0)
-        if mb > 1:
-            from .batching import MicroBatcher
-            eng.batcher = MicroBatcher(lambda key, items, w=self, e=eng: w._run_batch(key, items, e), max_batch=mb,
-                                       window_ms=float(os.environ.get("LCM_MICROBATCH_WINDOW_MS", "0") or 0))
-            eng.batch_sizes = tuple(eng.batcher.sizes)
+        eng = _Engine(type(self))
+        eng.device = device
+        eng.pipe = LcmHipPipeline(usd, vsd, ucfg, vcfg, device=device, schedule=sched)
+        with torch.cuda.stream(eng.pipe.stream):
+            self._load_text_encoders(eng, device, ckpt_root, clip_sd)
+        eng.refs = 1
+        self._engine = eng
+        self._load_styles(eng)
+        eng.start_batcher()
         if share:
             with _ENGINES_LOCK:
-                _ENGINES.setdefault(ekey, eng)
+                _ENGINES[ekey] = weakref.ref(eng)
         print(f"[hip] worker {worker_id} ({self.FAMILY}) loaded: {os.path.basename(ckpt)} ({format_name}) on {device} dtype=fp16 "
-              f"unet={self.pipe.unet.weight_bytes() / 1e9:.2f}GB vae={self.pipe.vae.weight_bytes() / 1e9:.2f}GB "
-              f"text={self._text_bytes() / 1e9:.2f}GB")
+              f"unet={eng.pipe.unet.weight_bytes() / 1e9:.2f}GB vae={eng.pipe.vae.weight_bytes() / 1e9:.2f}GB "
+              f"text={self._text_bytes(eng) / 1e9:.2f}GB")
+
+    # ---- the reference's attributes (tests/test_sdxl_worker.py:118-130), served from the shared engine --------------
+    @property
+    def pipe(self):
+        return self._engine.pipe if self._engine is not None else None
+
+    @property
+    def device(self):
+        return self._engine.device if self._engine is not None else None
+
+    @property
+    def dtype(self):
+        return torch.float16
+
+    @property
+    def _styles(self):
+        return self._engine.styles if self._engine is not None else {}
+
+    @property
+    def _active_style(self):
+        return self._engine.active_style
 
     # ---- style LoRAs (backends/cuda_worker.py:123-196) -----------------------------------------
-    def _load_styles(self):
+    @classmethod
+    def _load_styles(cls, eng):
         from ..lora import StyleAdapters
         from .styles import STYLE_REGISTRY
-        cad = int(self.pipe.unet.ctx_dim)
+        cad = int(eng.pipe.unet.ctx_dim)
         for sid, sd in STYLE_REGISTRY.items():
             if sd.required_cross_attention_dim is not None and int(sd.required_cross_attention_dim) != cad:
                 print(f"[hip] skip style '{sid}': incompatible cross_attention_dim (model={cad} style={sd.required_cross_attention_dim})")
@@ -199,57 +289,44 @@ class HipLcmWorker:
                 continue
             try:
                 from safetensors.torch import load_file
-                with torch.cuda.stream(self.pipe.stream):
-                    st = StyleAdapters(self.pipe.unet, self._text_encoders(), load_file(path))
-                self._styles[sid] = st
+                with torch.cuda.stream(eng.pipe.stream):
+                    st = StyleAdapters(eng.pipe.unet, cls._text_encoders(eng), load_file(path))
+                eng.styles[sid] = st
                 print(f"[hip] loaded style LoRA: {sid} -> {path} ({len(st.modules)} UNet + {st.text_modules} text-encoder modules, "
                       f"{len(st.skipped)} tensors skipped, {st.nbytes() / 1e6:.0f} MB)")
             except Exception as e:
                 print(f"[hip] FAILED to load style LoRA {sid}: {e!r}")
 
-    @property
-    def _active_style(self):
-        return self._engine.active_style
+    def _apply_style(self, style_id, level):
+        self._engine.apply_style(style_id, level)
 
-    def _apply_style(self, style_id, level, eng=None):
-        """Exclusive style selection; level 0 / unknown style = off.  Re-merges only when the selection changes."""
-        from .styles import STYLE_REGISTRY
-        want = None
-        if style_id and int(level) > 0 and style_id in self._styles:
-            want = (style_id, STYLE_REGISTRY[style_id].weight_for(level))
-        eng = eng or self._engine
-        if want == eng.active_style:
-            return
-        with torch.cuda.stream(self.pipe.stream):
-            if eng.active_style is not None and (want is None or want[0] != eng.active_style[0]):
-                self._styles[eng.active_style[0]].apply(0.0)
-            if want is not None:
-                self._styles[want[0]].apply(want[1])
-        eng.active_style = want
-
-    # ---- family hooks -----------------------------------------------------------------------
+    # ---- family hooks (operate on the engine: no worker object is ever captured by shared state) ----------------------
     def _synthetic_weights(self):
         return _weights.synthetic_unet(), None, _weights.synthetic_vae(), None
 
-    def _load_text_encoders(self, device, ckpt_root, clip_sd):
+    @staticmethod
+    def _load_text_encoders(eng, device, ckpt_root, clip_sd):
         # CLIP text encoder on the same kernels (checkpoint text_encoder/ when present, else synthetic CLIP-L weights)
-        self._encode = HipPromptEncoder(device, ckpt_root, clip_sd)
-        if self._encode.enc.D != self.pipe.unet.ctx_dim:
-            raise RuntimeError(f"text encoder width {self._encode.enc.D} != UNet cross_attention_dim {self.pipe.unet.ctx_dim}")
+        eng.encode = HipPromptEncoder(device, ckpt_root, clip_sd)
+        if eng.encode.enc.D != eng.pipe.unet.ctx_dim:
+            raise RuntimeError(f"text encoder width {eng.encode.enc.D} != UNet cross_attention_dim {eng.pipe.unet.ctx_dim}")
 
-    def _text_encoders(self):
-        return [self._encode.enc]
+    @staticmethod
+    def _text_encoders(eng):
+        return [eng.encode.enc]
 
-    def _text_bytes(self):
-        return self._encode.enc.weight_bytes()
+    @staticmethod
+    def _text_bytes(eng):
+        return eng.encode.enc.weight_bytes()
 
-    def _conditioning(self, reqs, width, height, guidance):
+    @staticmethod
+    def _conditioning(eng, reqs, width, height, guidance):
         """-> (prompt_embeds [B,77,ctx], kwargs for LcmHipPipeline.generate) for B requests of one batch."""
         B = len(reqs)
-        pe = self._encode([r.prompt for r in reqs])
+        pe = eng.encode([r.prompt for r in reqs])
         neg = None
-        if guidance > 1.0 and not self.pipe.unet.has_cond:
-            neg = self._encode([""]).expand(B, -1, -1)
+        if guidance > 1.0 and not eng.pipe.unet.has_cond:
+            neg = eng.encode([""]).expand(B, -1, -1)
         return pe, dict(negative_embeds=neg)
 
     # ------------------------------------------------------------------------------------------
@@ -264,26 +341,13 @@ class HipLcmWorker:
             style_id, level = None, 0
         return (width, height, int(req.num_inference_steps), float(req.guidance_scale), style_id, level)
 
-    def _run_batch(self, key, items, eng=None):
-        """One batched sampler pass for ``items`` = [(req, seed)], all of ``key``; -> per-item (rgb, pool8 row)."""
-        width, height, steps, g, style_id, level = key
-        eng = eng or self._engine
-        import time as _t
-        t0 = _t.perf_counter()
-        with eng.lock:                               # the pipeline, its plans and the merged weights are one resource
-            self._apply_style(style_id, level, eng)  # lazy: no re-merge while consecutive batches use the same style
-            reqs = [it[0] for it in items]
-            with torch.cuda.stream(self.pipe.stream):
-                pe, kw = self._conditioning(reqs, width, height, g)
-            t1 = _t.perf_counter()
-            noises = [it[2] for it in items] if all(len(it) > 2 and it[2] is not None for it in items) else None
-            out = self.pipe.generate(pe, [it[1] for it in items], width, height, steps, g, noises=noises, **kw)
-        t2 = _t.perf_counter()
-        if eng.timing is not None:                   # LCM_WORKER_TIMING=1: (batch, conditioning s, sampler call s, end time)
-            eng.timing.append((len(items), t1 - t0, t2 - t1, t2))
-        return [(out["rgb"][i], out["pool8"][i:i + 1]) for i in range(len(items))]
+    def _run_batch(self, key, items):
+        return self._engine.run_batch(key, items)
 
     def _submit(self, job):
+        eng = self._engine
+        if eng is None or eng.pipe is None:
+            raise RuntimeError("worker is closed")
         req = job.req
         key = self._job_key(req)                     # raises the reference's size error in the caller's thread
         seed = int(req.seed) if getattr(req, "seed", None) is not None else int(torch.randint(0, 100_000_000, (1,)).item())
@@ -291,11 +355,11 @@ class HipLcmWorker:
         # thread: pool threads do it in parallel and the GPU dispatcher's serial path shrinks by ~0.5 ms per request
         from ..pipeline import draw_noise
         noise = None
-        if key[0] % 64 == 0 and key[1] % 64 == 0 and key[0] > 0 and key[1] > 0:
-            noise = draw_noise(seed, key[1] // 8, key[0] // 8, key[2] - 1, self.pipe.sched.init_noise_sigma)
-        b = self._engine.batcher
+        if key[0] % 8 == 0 and key[1] % 8 == 0 and key[0] > 0 and key[1] > 0 and key[2] >= 1:
+            noise = draw_noise(seed, key[1] // 8, key[0] // 8, key[2] - 1, eng.pipe.sched.init_noise_sigma)
+        b = eng.batcher
         if b is None:
-            return self._run_batch(key, [(req, seed, noise)])[0], seed
+            return eng.run_batch(key, [(req, seed, noise)])[0], seed
         return b.submit(key, (req, seed, noise)).result(), seed
 
     def run_job(self, job) -> Tuple[bytes, int]:
@@ -323,26 +387,17 @@ class HipLcmWorker:
             while idx:
                 n = max(s for s in sizes if s <= len(idx))
                 part, idx = idx[:n], idx[n:]
-                for i, (rgb, _) in zip(part, self._run_batch(key, [(jobs[i].req, seeds[i]) for i in part])):
+                for i, (rgb, _) in zip(part, self._engine.run_batch(key, [(jobs[i].req, seeds[i]) for i in part])):
                     rgbs[i] = rgb
         with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
             pngs = list(ex.map(encode_png, rgbs))
         return list(zip(pngs, seeds))
 
     def close(self):
-        eng = getattr(self, "_engine", None)
-        if eng is None:
-            return
-        self._engine = None
-        if eng.release():                            # last worker on this engine: stop the dispatcher, free the graphs
-            if eng.batcher is not None:
-                eng.batcher.close()
-            pipe = getattr(self, "pipe", None)
-            if pipe is not None:
-                pipe.drop_plans()
-            if eng.first is not None:
-                eng.first.pipe = None
-            self.pipe = None
+        """Optional (the reference's pool never calls it): detach from the engine now instead of at garbage collection."""
+        eng, self._engine = getattr(self, "_engine", None), None
+        if eng is not None:
+            eng.release()
 
     def __del__(self):
         try:
@@ -365,10 +420,11 @@ class HipLcmSDXLWorker(HipLcmWorker):
         return (_weights.synthetic_state_dict(_weights.unet_param_spec(ucfg), 0), ucfg,
                 _weights.synthetic_state_dict(_weights.vae_param_spec(vcfg), 1), vcfg)
 
-    def _load_text_encoders(self, device, ckpt_root, clip_sd):
+    @staticmethod
+    def _load_text_encoders(eng, device, ckpt_root, clip_sd):
         from ..clip import CLIP_BIGG, CLIP_L, ClipTextHip, HashTokenizer, load_clip_dir, synthetic_clip
         from ..prompt import _BpeTokenizer
-        self._enc, self._tok = [], []
+        eng.enc, eng.tok = [], []
         for idx, (sub, tsub, cfg0, seed) in enumerate((("text_encoder", "tokenizer", CLIP_L, 2),
                                                        ("text_encoder_2", "tokenizer_2", CLIP_BIGG, 3))):
             d = os.path.join(ckpt_root, sub) if ckpt_root else None
@@ -385,26 +441,29 @@ class HipLcmSDXLWorker(HipLcmWorker):
                 cfg = dict(cfg0, **cfg)
             else:
                 sd, cfg = synthetic_clip(cfg0, seed=seed), cfg0
-            self._enc.append(ClipTextHip(sd, cfg, device=device))
+            eng.enc.append(ClipTextHip(sd, cfg, device=device))
             td = os.path.join(ckpt_root, tsub) if ckpt_root else None
-            self._tok.append(_BpeTokenizer(td) if td and os.path.isdir(td) else HashTokenizer(cfg["vocab_size"]))
-        if self._enc[0].D + self._enc[1].D != self.pipe.unet.ctx_dim:
+            eng.tok.append(_BpeTokenizer(td) if td and os.path.isdir(td) else HashTokenizer(cfg["vocab_size"]))
+        if eng.enc[0].D + eng.enc[1].D != eng.pipe.unet.ctx_dim:
             raise RuntimeError("text encoder widths do not add up to the UNet cross_attention_dim")
 
-    def _text_encoders(self):
-        return list(self._enc)
+    @staticmethod
+    def _text_encoders(eng):
+        return list(eng.enc)
 
-    def _text_bytes(self):
-        return sum(e.weight_bytes() for e in self._enc)
+    @staticmethod
+    def _text_bytes(eng):
+        return sum(e.weight_bytes() for e in eng.enc)
 
-    def _conditioning(self, reqs, width, height, guidance):
+    @staticmethod
+    def _conditioning(eng, reqs, width, height, guidance):
         prompts = [r.prompt for r in reqs]
-        h1 = self._enc[0].forward(self._tok[0](prompts), output="penultimate")
-        h2, pooled = self._enc[1].forward(self._tok[1](prompts), output="penultimate", pooled=True)
+        h1 = eng.enc[0].forward(eng.tok[0](prompts), output="penultimate")
+        h2, pooled = eng.enc[1].forward(eng.tok[1](prompts), output="penultimate", pooled=True)
         pe = torch.cat([h1, h2], dim=-1)
         tids = torch.tensor([[float(height), float(width), 0.0, 0.0, float(height), float(width)]] * len(reqs))
         kw = dict(added=(pooled, tids))
-        if guidance > 1.0 and not self.pipe.unet.has_cond:
+        if guidance > 1.0 and not eng.pipe.unet.has_cond:
             kw["negative_embeds"] = torch.zeros_like(pe)
             kw["negative_added"] = (torch.zeros_like(pooled), tids)
         return pe, kw

@@ -135,13 +135,13 @@ class ClipTextHip:
             if output == "penultimate" and i == self.L - 1:
                 pen = x.clone()                                    # hidden_states[-2]: input of the last layer (device copy)
             ops.layernorm(x, w[f"{i}.ln1.g"], w[f"{i}.ln1.b"], n, M, D, self.cfg["layer_norm_eps"])
-            ops.gemm(n, w[f"{i}.qkv.w"], qkv, bias=w[f"{i}.qkv.b"])
+            ops.gemm(n, w[f"{i}.qkv.w"], qkv, bias=w[f"{i}.qkv.b"], img_rows=S)
             ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], a, B, H, S, S, d, ldq=3 * D, ldk=3 * D, ldv=3 * D,
                           ldo=D, causal=True)
-            ops.gemm(a, w[f"{i}.o.w"], x, bias=w[f"{i}.o.b"], res=x)
+            ops.gemm(a, w[f"{i}.o.w"], x, bias=w[f"{i}.o.b"], res=x, img_rows=S)
             ops.layernorm(x, w[f"{i}.ln2.g"], w[f"{i}.ln2.b"], n, M, D, self.cfg["layer_norm_eps"])
-            ops.gemm(n, w[f"{i}.fc1.w"], h, bias=w[f"{i}.fc1.b"], epilogue=self.act)
-            ops.gemm(h, w[f"{i}.fc2.w"], x, bias=w[f"{i}.fc2.b"], res=x)
+            ops.gemm(n, w[f"{i}.fc1.w"], h, bias=w[f"{i}.fc1.b"], epilogue=self.act, img_rows=S)
+            ops.gemm(h, w[f"{i}.fc2.w"], x, bias=w[f"{i}.fc2.b"], res=x, img_rows=S)
         if output == "penultimate":
             hidden = (pen if pen is not None else x.clone()).reshape(B, S, D)
         else:

@@ -36,6 +36,26 @@ struct HaloParams {
 
 static __device__ __attribute__((aligned(256))) half_t g_zero_page_h[128];
 
+// Canonical GroupNorm-statistics slabs of a convolution output (see igemm_epilogue): a slab is the 32-pixel patch
+// (32/TW rows x TW columns, TW fixed by the image width) that one fragment pair of a wave covers, indexed by its
+// position in the image -- the same pixels whether the workgroup tile is 8 or 4 rows high.  Phase-decomposed upsample
+// convolutions index (input patch, phase).  Patches past the last image row carry no slab.
+template <int TH, int TW, int PH>
+__device__ __forceinline__ void halo_slabs(int (&slab_of)[TH * TW / 64], int wm, int bimg, int y0, int x0, int IH, int IW, int phase) {
+    constexpr int RS = 32 / TW;                       // rows per slab
+    const int sx = (IW + TW - 1) / TW, sy = (IH + RS - 1) / RS;
+#pragma unroll
+    for (int bp = 0; bp < TH * TW / 64; ++bp) {
+        const int y = y0 + wm * (TH / 2) + bp * RS;
+        const int idx = (bimg * sy + y / RS) * sx + x0 / TW;
+        slab_of[bp] = y < IH ? (PH ? idx * 4 + phase : idx) : -1;
+    }
+}
+static inline int halo_slabs_per_image(int IH, int IW, int TW, bool ph) {
+    const int rs = 32 / TW;
+    return ((IH + rs - 1) / rs) * ((IW + TW - 1) / TW) * (ph ? 4 : 1);
+}
+
 template <int TH, int TW, int BN, int XFORM, int PH>
 __global__ __launch_bounds__(256, 3) void conv_halo_kernel(HaloParams hp) {
     constexpr int NT = PH ? 4 : 9;
@@ -197,9 +217,12 @@ __global__ __launch_bounds__(256, 3) void conv_halo_kernel(HaloParams hp) {
     for (int b = 0; b < TM; ++b) {
         const int q = (wm * TM + b) * 16 + frow;
         const int y = y0 + q / TW, x = x0 + q % TW;
-        m_of[b] = (y < IH && x < IW) ? (PH ? (bimg * hp.H + 2 * y + py) * hp.W + 2 * x + px : (bimg * hp.H + y) * hp.W + x) : -1;
+        if (PH) m_of[b] = (y < IH && x < IW && 2 * y + py < hp.H && 2 * x + px < hp.W) ? (bimg * hp.H + 2 * y + py) * hp.W + 2 * x + px : -1;
+        else m_of[b] = (y < IH && x < IW) ? (bimg * hp.H + y) * hp.W + x : -1;
     }
-    igemm_epilogue<BM, BN>(p, acc, m_of, n_base + wn * (BN / 2), fq, 0, mt4 * 2 + wm);
+    int slab_of[BM / 64];
+    halo_slabs<TH, TW, PH>(slab_of, wm, bimg, y0, x0, IH, IW, phase);
+    igemm_epilogue<BM, BN>(p, acc, m_of, n_base + wn * (BN / 2), fq, 0, slab_of);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -400,14 +423,17 @@ __global__ __launch_bounds__(256, 2) void conv_halo_pipe_kernel(HaloParams hp) {
     for (int b = 0; b < TM; ++b) {
         const int q = (wm * TM + b) * 16 + frow;
         const int y = y0 + q / TW, x = x0 + q % TW;
-        m_of[b] = (y < IH && x < IW) ? (PH ? (bimg * hp.H + 2 * y + py) * hp.W + 2 * x + px : (bimg * hp.H + y) * hp.W + x) : -1;
+        if (PH) m_of[b] = (y < IH && x < IW && 2 * y + py < hp.H && 2 * x + px < hp.W) ? (bimg * hp.H + 2 * y + py) * hp.W + 2 * x + px : -1;
+        else m_of[b] = (y < IH && x < IW) ? (bimg * hp.H + y) * hp.W + x : -1;
     }
-    igemm_epilogue<BM, BN>(p, acc, m_of, n_base + wn * (BN / 2), fq, 0, mt4 * 2 + wm);
+    int slab_of[BM / 64];
+    halo_slabs<TH, TW, PH>(slab_of, wm, bimg, y0, x0, IH, IW, phase);
+    igemm_epilogue<BM, BN>(p, acc, m_of, n_base + wn * (BN / 2), fq, 0, slab_of);
 }
 
 // split-K combine kernel lives in igemm.hip
 extern void lcm_launch_splitk_reduce(IgemmParams& p, hipStream_t s);
-extern int lcm_reduce_rows(int M, int hw);
+extern int lcm_reduce_rows(int hw);
 extern float* lcm_splitk_workspace(long long* bytes);
 extern void lcm_tuning(int* target_wgs, int* max_splits, int* min_wgs);
 extern bool lcm_plan_get(int kind, int M, int N, int K, int aux, int* bm, int* bn, int* splits, int* variant);
@@ -466,47 +492,75 @@ static void launch_halo(HaloParams& hp, hipStream_t s, int force) {     // force
     lcm_prof_stop(s);
 }
 
-// returns 0 when launched, 1 when the shape is not handled here (caller falls back to the row-gather igemm)
+// Tile + split candidates of the halo conv.  fixed_splits < 0: choose the split factor as well (the canonical
+// K-partition heuristic, evaluated on ONE image); >= 1: partition given, pick the most efficient tile that fills the chip.
+struct HaloPick { int bm, bn, splits; };
+static HaloPick halo_pick(int B, int IH, int IW, int PHM, int TW, long long M, int N, int nchunks, int fixed_splits) {
+    int target, max_splits, min_wgs;
+    lcm_tuning(&target, &max_splits, &min_wgs);
+    const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
+    HaloPick best = {0, 0, fixed_splits > 0 ? fixed_splits : 1};
+    long long best_wgs = -1;
+    for (int c = 0; c < 4; ++c) {
+        const int cbm = cand[c][0], cbn = cand[c][1];
+        if (N % cbn) continue;
+        if (TW == 8 && cbm == 128) continue;
+        const int th = cbm / TW;
+        const long long mt = (long long)B * ((IH + th - 1) / th) * ((IW + TW - 1) / TW) * PHM;
+        if ((long long)mt * cbm > 2ll * M && cbm == 128) continue;      // tiles that would be mostly padding
+        const long long tiles = mt * (N / cbn);
+        int sp = fixed_splits > 0 ? fixed_splits : 1;
+        if (fixed_splits < 0 && tiles < min_wgs && nchunks >= 2) {
+            sp = (int)((target + tiles - 1) / tiles);
+            if (sp > nchunks) sp = nchunks;
+            if (sp > max_splits) sp = max_splits;
+        }
+        const long long wgs = tiles * sp;
+        if (wgs >= min_wgs) return {cbm, cbn, sp};
+        if (wgs > best_wgs) { best_wgs = wgs; best = {cbm, cbn, sp}; }
+    }
+    return best;
+}
+
+static inline int halo_tw(int IW) { return (IW % 16 == 0 || IW > 16) ? 16 : 8; }
+
+// canonical split factor of a stride-1 3x3 convolution with this PER-IMAGE shape (see igemm.hip, "What decides the numbers")
+int lcm_canonical_splits_halo(int m_img, int N, int K, int IH, int IW, int W, int ph, int xform) {      // W: output width
+    const int nchunks = (K / (ph ? 4 : 9)) >> 6;
+    int pbm, pbn, psp, pv;
+    int sp = lcm_plan_get(2, m_img, N, K, (W << 1) | (xform ? 1 : 0), &pbm, &pbn, &psp, &pv)
+                 ? psp : halo_pick(1, IH, IW, ph ? 4 : 1, halo_tw(IW), m_img, N, nchunks, -1).splits;
+    if (sp > nchunks) sp = nchunks;
+    return sp < 1 ? 1 : sp;
+}
+
+// returns 0 when launched, 1 when the shape is not handled here, < 0 on error
 int lcm_conv_halo_launch(HaloParams& hp, int B, hipStream_t s, int* slabs_per_image) {
     IgemmParams& p = hp.g;
     const bool ph = p.ups == 2;                      // phase-decomposed upsample conv: tiles walk the INPUT image, x4 phases
     const int IH = ph ? p.Hin : hp.H, IW = ph ? p.Win : hp.W, PHM = ph ? 4 : 1;
-    const int TW = (IW % 16 == 0 || IW > 16) ? 16 : 8;
-    int target, max_splits, min_wgs;
-    lcm_tuning(&target, &max_splits, &min_wgs);
+    const int TW = halo_tw(IW);
     long long ws_bytes = 0;
     p.ws = lcm_splitk_workspace(&ws_bytes);
     const int nchunks = p.Cin >> 6;
-    // candidates (BM, BN) by per-FLOP efficiency; split over channel chunks fills the chip for small images
-    const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
-    int bm = 0, bn = 0, splits = 1, force = 0;
-    long long best = -1;
-    for (int c = 0; c < 4; ++c) {
-        const int cbm = cand[c][0], cbn = cand[c][1];
-        if (p.N % cbn) continue;
-        if (TW == 8 && cbm == 128) continue;
-        const int th = cbm / TW;
-        const long long mt = (long long)B * ((IH + th - 1) / th) * ((IW + TW - 1) / TW) * PHM;
-        // skip tiles that would be mostly padding
-        if ((long long)mt * cbm > 2ll * p.M && cbm == 128) continue;
-        const long long tiles = mt * (p.N / cbn);
-        int sp = 1;
-        if (p.ws && tiles < min_wgs && nchunks >= 2) {
-            sp = (int)((target + tiles - 1) / tiles);
-            if (sp > nchunks) sp = nchunks;
-            if (sp > max_splits) sp = max_splits;
-            while (sp > 1 && (long long)sp * p.M * p.N * 4 > ws_bytes) --sp;
-        }
-        const long long wgs = tiles * sp;
-        if (wgs >= min_wgs) { bm = cbm; bn = cbn; splits = sp; break; }
-        if (wgs > best) { best = wgs; bm = cbm; bn = cbn; splits = sp; }
+    const int m_img = p.M / B;
+    p.img_rows = m_img;
+    // the K partition: a function of the per-image problem only
+    const int splits = p.ws ? lcm_canonical_splits_halo(m_img, p.N, p.K, IH, IW, hp.W, ph ? 1 : 0, hp.gn_scale ? 1 : 0) : 1;
+    if (splits > 1 && (long long)splits * p.M * p.N * 4 > ws_bytes) {
+        lcm_set_error("split-K workspace too small: %d x %d x %d fp32 slabs need %lld MB, have %lld MB "
+                      "(lcm_set_workspace / LCM_SPLITK_WS_MB)", splits, p.M, p.N,
+                      ((long long)splits * p.M * p.N * 4 + (1 << 20) - 1) >> 20, ws_bytes >> 20);
+        return LCM_EINVAL;
     }
+    // tile / variant: launch parameters (plan entry of the total shape, else the occupancy heuristic)
+    HaloPick hk = halo_pick(B, IH, IW, PHM, TW, p.M, p.N, nchunks, splits);
+    int bm = hk.bm, bn = hk.bn, force = 0;
     {   // autotuned plan for this shape, if any (kind 2; aux = (W << 1) | xform)
         int pbm, pbn, psp, pv;
         if (lcm_plan_get(2, p.M, p.N, p.K, (hp.W << 1) | (hp.gn_scale ? 1 : 0), &pbm, &pbn, &psp, &pv) && p.N % pbn == 0 &&
             !(TW == 8 && pbm == 128)) {
-            if (psp > 1 && (!p.ws || (long long)psp * p.M * p.N * 4 > ws_bytes || psp > nchunks)) psp = 1;
-            bm = pbm; bn = pbn; splits = psp;
+            bm = pbm; bn = pbn;
             force = (pv >= 1 && pv <= 3) ? pv : 0;
         }
     }
@@ -517,13 +571,13 @@ int lcm_conv_halo_launch(HaloParams& hp, int B, hipStream_t s, int* slabs_per_im
     if (p.stats) {   // fused GroupNorm statistics of the output
         if (p.N > 2048) p.stats = nullptr;
         else if (splits > 1) {
-            p.reduce_rows = lcm_reduce_rows(p.M, hp.H * hp.W);
+            p.reduce_rows = lcm_reduce_rows(hp.H * hp.W);
             if (slabs_per_image) *slabs_per_image = hp.H * hp.W / p.reduce_rows;
         } else if (slabs_per_image) {
-            *slabs_per_image = 2 * (p.mtiles / B);      // one slab per (patch, wave row)
+            *slabs_per_image = halo_slabs_per_image(IH, IW, TW, ph);      // canonical 32-pixel slabs (halo_slabs)
         }
     }
-    if (splits > 1 && p.reduce_rows <= 0) p.reduce_rows = lcm_reduce_rows(p.M, 0);
+    if (splits > 1 && p.reduce_rows <= 0) p.reduce_rows = lcm_reduce_rows(hp.H * hp.W);
     const bool xf = hp.gn_scale != nullptr;
     if (ph && xf) return 1;
 #define HALO_CASE(TH_, TW_, BN_)                                                           \

@@ -153,7 +153,13 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
         const int m = m_base + wm * (BM / 2) + b * 16 + frow;
         m_of[b] = m < p.M ? m : -1;
     }
-    igemm_epilogue<BM, BN>(p, acc, m_of, n_base + wn * (BN / 2), fq, z, mt * 2 + wm);
+    int slab_of[BM / 64];
+#pragma unroll
+    for (int bp = 0; bp < BM / 64; ++bp) {
+        const int r = m_base + wm * (BM / 2) + bp * 32;
+        slab_of[bp] = r < p.M ? (r >> 5) : -1;
+    }
+    igemm_epilogue<BM, BN>(p, acc, m_of, n_base + wn * (BN / 2), fq, z, slab_of);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -324,7 +330,13 @@ __global__ __launch_bounds__(256, S == 1 ? (BM + BN < 256 ? 4 : 3) : 2) void ige
                 const int m = m_base + wm * (BM / 2) + b * 16 + frow;
                 m_of[b] = m < p.M ? m : -1;
             }
-            igemm_epilogue<BM, BN>(p, acc, m_of, (nt0 + ni_cur) * BN + wn * (BN / 2), fq, z, mt * 2 + wm);
+            int slab_of[BM / 64];
+#pragma unroll
+            for (int bp = 0; bp < BM / 64; ++bp) {
+                const int r = m_base + wm * (BM / 2) + bp * 32;
+                slab_of[bp] = r < p.M ? (r >> 5) : -1;
+            }
+            igemm_epilogue<BM, BN>(p, acc, m_of, (nt0 + ni_cur) * BN + wn * (BN / 2), fq, z, slab_of);
             ++ni_cur;
 #pragma unroll
             for (int a = 0; a < TN; ++a)
@@ -408,16 +420,17 @@ extern "C" int lcm_set_workspace(void* ptr, int64_t bytes) {
     g_ws_bytes[dev] = ptr ? bytes : 0;
     return LCM_OK;
 }
-// rows per reduce workgroup: a power of two <= 32 that divides `hw` (so a slab never straddles two images when the
-// fused statistics are on) and leaves >= ~128 workgroups
-int lcm_reduce_rows(int M, int hw) {
+// rows per reduce workgroup: a power of two <= 32 that divides `hw` = output rows PER IMAGE (a slab never straddles two
+// images, and the slab structure -- hence the order in which the fused statistics are summed -- depends on the image
+// shape only, never on how many images share the launch) and leaves >= ~128 workgroups per image where it can
+int lcm_reduce_rows(int hw) {
     int rs = 32;
-    while (rs > 1 && (M / rs < 128 || (hw > 0 && hw % rs))) rs >>= 1;
+    while (rs > 1 && (hw / rs < 128 || hw % rs)) rs >>= 1;
     return rs;
 }
 
 void lcm_launch_splitk_reduce(IgemmParams& p, hipStream_t s) {
-    if (p.reduce_rows <= 0) p.reduce_rows = lcm_reduce_rows(p.M, 0);
+    if (p.reduce_rows <= 0) p.reduce_rows = lcm_reduce_rows(p.img_rows > 0 ? p.img_rows : p.M);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((p.M + p.reduce_rows - 1) / p.reduce_rows)), dim3(RED_THREADS), 0, s, p);
 }
 
@@ -461,9 +474,16 @@ bool lcm_plan_get(int kind, int M, int N, int K, int aux, int* bm, int* bn, int*
     return true;
 }
 
-// Tile + split-K selection.  Candidates in order of per-FLOP efficiency (128x128, 128x64, 64x128, 64x64);
-// split-K (deterministic slab reduce) tops a launch up to >= ~1.5 workgroups per CU when the output alone
-// has too few tiles (deep-K, small-M layers: the low-resolution UNet levels at batch 1).
+// Tile + split-K selection.
+//
+// What decides the numbers and what does not.  The fp32 summation order of an output element is fixed by the K
+// partition alone (a workgroup walks its k-tiles in order; the split-K combine adds the slabs in slab order); tile
+// shape, ring depth and kernel variant are pure launch parameters, and the fused statistics are written per canonical
+// 32-pixel slab whatever the tile (igemm_epilogue).  So the split factor is a function of the PER-IMAGE problem
+// (kind, rows per image, N, K) -- from the plan table entry of that per-image shape when there is one, else from the
+// deterministic heuristic below -- and is never chosen by timing at run time nor from the batch size: a request gets
+// the same bits alone, in a batch of 8, in another process and on another box.  Tile / variant come from the plan
+// entry of the TOTAL shape (tuned freely) or the occupancy heuristic.
 struct TilePick { int bm, bn, splits; };
 static int g_target_wgs = 384, g_max_splits = 16, g_min_wgs = 256;
 static int g_variant = -1;     // -1: auto (1 stage when >= 4 workgroups per CU are available, else 2); 0: register-staged
@@ -494,10 +514,12 @@ extern "C" int lcm_set_tuning(int target_wgs, int max_splits, int min_wgs) {
     return LCM_OK;
 }
 
-static TilePick pick_tile(int M, int N, int K, int batch, long long ws_bytes, bool allow_split) {
+// fixed_splits < 0: choose the split factor too (the canonical-partition heuristic, called with the per-image shape);
+// >= 1: the partition is given, pick the most efficient tile that fills the chip with it
+static TilePick pick_tile(int M, int N, int K, int batch, int fixed_splits) {
     const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
     const int nk = K >> 6;
-    TilePick best = {64, 64, 1};
+    TilePick best = {64, 64, fixed_splits > 0 ? fixed_splits : 1};
     long long best_wgs = -1;
     for (int c = 0; c < 4; ++c) {
         const int bm = cand[c][0], bn = cand[c][1];
@@ -505,12 +527,11 @@ static TilePick pick_tile(int M, int N, int K, int batch, long long ws_bytes, bo
         if (bm == 128 && M < 128) continue;
         if (bm == 64 && bn == 128 && M >= 128) continue;
         const long long tiles = (long long)((M + bm - 1) / bm) * (N / bn) * batch;
-        int splits = 1;
-        if (allow_split && batch == 1 && tiles < g_min_wgs && nk >= 16) {
+        int splits = fixed_splits > 0 ? fixed_splits : 1;
+        if (fixed_splits < 0 && batch == 1 && tiles < g_min_wgs && nk >= 16) {
             splits = (int)((g_target_wgs + tiles - 1) / tiles);
             if (splits > nk / 8) splits = nk / 8;
             if (splits > g_max_splits) splits = g_max_splits;
-            while (splits > 1 && (long long)splits * M * N * 4 > ws_bytes) --splits;
             if (splits < 1) splits = 1;
         }
         const long long wgs = tiles * splits;
@@ -520,8 +541,30 @@ static TilePick pick_tile(int M, int N, int K, int batch, long long ws_bytes, bo
     return best;
 }
 
+// canonical split factor of a GEMM-kind contraction (kind 0: linear / 1x1, kind 1: row-gather 3x3) with `m_img`
+// output rows per image
+static int canonical_splits_gemm(int kind, int m_img, int N, int K) {
+    int pbm, pbn, psp, pv;
+    int sp = lcm_plan_get(kind, m_img, N, K, 1, &pbm, &pbn, &psp, &pv) ? psp : pick_tile(m_img, N, K, 1, -1).splits;
+    if (sp > (K >> 6)) sp = K >> 6;
+    return sp < 1 ? 1 : sp;
+}
+
+int lcm_canonical_splits_halo(int m_img, int N, int K, int IH, int IW, int W, int ph, int xform);
+
+// The K partition the library will use for a contraction of this per-image shape (the autotuner tunes tile / variant
+// around it).  kind 2 (LDS-halo 3x3): aux = (output width << 1) | gn-fused flag, ph = 1 for the phase-decomposed
+// upsample convolution.
+extern "C" int lcm_canonical_splits(int kind, int m_img, int N, int K, int aux, int ph) {
+    if (kind == 0 || kind == 1) return canonical_splits_gemm(kind, m_img, N, K);
+    const int W = aux >> 1;
+    if (kind != 2 || W <= 0 || m_img % W) { lcm_set_error("canonical_splits: bad key"); return LCM_EINVAL; }
+    const int H = m_img / W;
+    return lcm_canonical_splits_halo(m_img, N, K, ph ? (H + 1) / 2 : H, ph ? (W + 1) / 2 : W, W, ph, aux & 1);
+}
+
 extern "C" int lcm_gemm_tile_config(int M, int N, int batch) {
-    TilePick t = pick_tile(M, N, 64, batch, 0, false);
+    TilePick t = pick_tile(M, N, 64, batch, 1);
     return t.bm * 1000 + t.bn;
 }
 
@@ -604,47 +647,58 @@ static int launch_cfg(IgemmParams& p, int batch, int splits, int plan_variant, h
     return LCM_OK;
 }
 
-// Fused-statistics bookkeeping: `stats_hw` = rows per image of the output.  On return *slabs_per_image is the
-// number of [N][2] partial rows the launch wrote per image (0 = statistics not produced: the tile shape would
-// straddle images; the caller then runs the standalone statistics kernel).
+// Fused-statistics bookkeeping: `img_rows` = output rows per image.  On return *slabs_per_image is the number of
+// [N][2] partial rows the launch wrote per image (0 = statistics not produced; the caller then runs the standalone
+// statistics kernel).
 template <int MODE>
-static int launch_igemm(IgemmParams& p, int batch, hipStream_t s, int stats_hw = 0, int* slabs_per_image = nullptr) {
+static int launch_igemm(IgemmParams& p, int batch, hipStream_t s, int img_rows, bool allow_split, bool want_stats,
+                        int* slabs_per_image) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     p.ws = (dev >= 0 && dev < 16) ? g_ws[dev] : nullptr;
     const long long wsb = p.ws ? g_ws_bytes[dev] : 0;
-    TilePick t = pick_tile(p.M, p.N, p.K, batch, wsb, p.ws != nullptr && p.epi == 0);
+    if (img_rows <= 0 || p.M % img_rows) img_rows = p.M;
+    p.img_rows = img_rows;
+    int splits = 1;
+    if (allow_split && p.ws && p.epi == 0 && batch == 1) {      // no workspace registered: the library never splits
+        splits = canonical_splits_gemm(MODE, img_rows, p.N, p.K);
+        if (splits > 1 && (long long)splits * p.M * p.N * 4 > wsb) {
+            lcm_set_error("split-K workspace too small: %d x %d x %d fp32 slabs need %lld MB, have %lld MB "
+                          "(lcm_set_workspace / LCM_SPLITK_WS_MB)", splits, p.M, p.N,
+                          ((long long)splits * p.M * p.N * 4 + (1 << 20) - 1) >> 20, wsb >> 20);
+            return LCM_EINVAL;
+        }
+    }
+    TilePick t = pick_tile(p.M, p.N, p.K, batch, splits);
     int variant = -1, pbm, pbn, psp, pv;
     // the 160-wide tile (N = 320 / 640 / 960 ...: fewer L2->LDS bytes per FLOP than 64-wide) exists for the plain GEMM only;
     // its 5 n-fragments per wave cannot carry the GEGLU value/gate pairing
     if (lcm_plan_get(MODE, p.M, p.N, p.K, batch, &pbm, &pbn, &psp, &pv) && p.N % pbn == 0 &&
-        !(pbn == 160 && (MODE != 0 || p.epi == 1))) {
-        if (psp > 1 && (p.epi != 0 || batch != 1 || (long long)psp * p.M * p.N * 4 > wsb || psp > (p.K >> 6))) psp = 1;
-        t = {pbm, pbn, psp};
+        !(pbn == 160 && (MODE != 0 || p.epi == 1)) && !(pbm == 128 && p.M < 128)) {
+        t.bm = pbm; t.bn = pbn;
         variant = pv;
     }
     if (slabs_per_image) *slabs_per_image = 0;
+    p.stats = want_stats ? p.stats : nullptr;
     if (p.stats) {
-        bool ok = stats_hw > 0 && p.epi == 0 && batch == 1 && p.N <= 2048 && p.M % stats_hw == 0;
-        if (ok && t.splits > 1) {
-            p.reduce_rows = lcm_reduce_rows(p.M, stats_hw);
-            if (slabs_per_image) *slabs_per_image = stats_hw / p.reduce_rows;
+        const bool ok = p.epi == 0 && batch == 1 && p.N <= 2048 && img_rows % 32 == 0;
+        if (ok && splits > 1) {
+            p.reduce_rows = lcm_reduce_rows(img_rows);
+            if (slabs_per_image) *slabs_per_image = img_rows / p.reduce_rows;
         } else if (ok) {
-            if (stats_hw % t.bm != 0 && t.bm == 128 && stats_hw % 64 == 0) t.bm = 64;     // keep tiles inside one image
-            ok = stats_hw % t.bm == 0;
-            if (ok && slabs_per_image) *slabs_per_image = stats_hw / (t.bm / 2);
+            if (slabs_per_image) *slabs_per_image = img_rows / 32;       // canonical 32-row slabs (igemm_epilogue)
         }
         if (!ok) p.stats = nullptr;
     }
-    if (t.splits > 1 && p.reduce_rows <= 0) p.reduce_rows = lcm_reduce_rows(p.M, 0);
+    if (splits > 1 && p.reduce_rows <= 0) p.reduce_rows = lcm_reduce_rows(img_rows);
     const int code = t.bm * 1000 + t.bn;
     switch (code) {
-        case 128128: return launch_cfg<128, 128, MODE>(p, batch, t.splits, variant, s);
-        case 128064: return launch_cfg<128, 64, MODE>(p, batch, t.splits, variant, s);
-        case 64128: return launch_cfg<64, 128, MODE>(p, batch, t.splits, variant, s);
-        case 128160: if constexpr (MODE == 0) return launch_cfg<128, 160, MODE>(p, batch, t.splits, variant, s);
-        case 64160: if constexpr (MODE == 0) return launch_cfg<64, 160, MODE>(p, batch, t.splits, variant, s);
-        default: return launch_cfg<64, 64, MODE>(p, batch, t.splits, variant, s);
+        case 128128: return launch_cfg<128, 128, MODE>(p, batch, splits, variant, s);
+        case 128064: return launch_cfg<128, 64, MODE>(p, batch, splits, variant, s);
+        case 64128: return launch_cfg<64, 128, MODE>(p, batch, splits, variant, s);
+        case 128160: if constexpr (MODE == 0) return launch_cfg<128, 160, MODE>(p, batch, splits, variant, s);
+        case 64160: if constexpr (MODE == 0) return launch_cfg<64, 160, MODE>(p, batch, splits, variant, s);
+        default: return launch_cfg<64, 64, MODE>(p, batch, splits, variant, s);
     }
 }
 
@@ -652,8 +706,8 @@ extern "C" int lcm_gemm_f16(const void* A, int lda, const void* A2, int lda2, in
                             const void* W, const void* bias, const void* rowadd, int ld_rowadd, int rows_per_batch,
                             const void* res, int ldr, void* out, int ldo,
                             int M, int N, int K, int epilogue, float out_scale,
-                            int batch, int64_t strideA, int64_t strideW, int64_t strideO,
-                            void* stats_out, int stats_hw, int* slabs_per_image, void* stream) {
+                            int batch, int64_t strideA, int64_t strideW, int64_t strideO, int img_rows,
+                            void* stats_out, int* slabs_per_image, void* stream) {
     LCM_REQUIRE(A && W && out, "gemm: null pointer");
     LCM_REQUIRE(M > 0 && N > 0 && K > 0 && batch > 0, "gemm: bad shape M=%d N=%d K=%d batch=%d", M, N, K, batch);
     LCM_REQUIRE(K % 64 == 0, "gemm: K=%d must be a multiple of 64", K);
@@ -673,7 +727,9 @@ extern "C" int lcm_gemm_f16(const void* A, int lda, const void* A2, int lda2, in
     p.epi = epilogue; p.out_scale = out_scale;
     p.strideA = strideA; p.strideW = strideW; p.strideO = strideO;
     p.stats = (float*)stats_out;
-    return launch_igemm<0>(p, batch, (hipStream_t)stream, stats_hw, slabs_per_image);
+    // strided (batched-matrix) calls never split: whether a request runs alone or in a batch must not change its K partition
+    const bool allow_split = batch == 1 && strideA == 0 && strideW == 0 && strideO == 0;
+    return launch_igemm<0>(p, batch, (hipStream_t)stream, img_rows, allow_split, stats_out != nullptr, slabs_per_image);
 }
 
 struct HaloParams {
@@ -702,9 +758,14 @@ extern "C" int lcm_conv3x3_gn_f16(const void* in, int C1, const void* in2, int C
     IgemmParams& p = hp.g;
     p.A = (const half_t*)in; p.A2 = (const half_t*)in2; p.W = (const half_t*)W; p.bias = (const half_t*)bias;
     p.rowadd = (const half_t*)rowadd; p.res = (const half_t*)res; p.out = (half_t*)out;
+    // ups flags: +4 / +8 crop the upsampled output to 2*Hin-1 rows / 2*Win-1 columns (Upsample2D called with the odd-sized
+    // skip's output_size: F.interpolate(size=2h-1, mode="nearest") picks source floor(d*h/(2h-1)) == d>>1 for every d)
+    const int crop_h = (ups >> 2) & 1, crop_w = (ups >> 3) & 1;
+    ups &= 3;
     LCM_REQUIRE(ups >= 0 && ups <= 2 && !(ups == 2 && gn_scale), "conv3x3_gn: ups=%d (2 = phase-packed weights, no fused GroupNorm)", ups);
+    LCM_REQUIRE(ups != 0 || (!crop_h && !crop_w), "conv3x3_gn: output crop flags need an upsampling mode");
     p.Hin = Hin; p.Win = Win; p.Cin = Cin; p.stride = 1; p.ups = ups;
-    hp.H = ups ? 2 * Hin : Hin; hp.W = ups ? 2 * Win : Win;
+    hp.H = ups ? 2 * Hin - crop_h : Hin; hp.W = ups ? 2 * Win - crop_w : Win;
     p.Hout = hp.H; p.Wout = hp.W;
     p.M = B * hp.H * hp.W; p.N = Cout; p.K = (ups == 2 ? 4 : 9) * Cin;
     p.ldo = Cout; p.ldr = Cout; p.ld_rowadd = ld_rowadd; p.rows_per_batch = hp.H * hp.W;
@@ -712,7 +773,9 @@ extern "C" int lcm_conv3x3_gn_f16(const void* in, int C1, const void* in2, int C
     hp.C1 = C1; hp.gn_scale = (const float*)gn_scale; hp.gn_shift = (const float*)gn_shift; hp.silu = silu;
     p.stats = (float*)stats_out;
     if (slabs_per_image) *slabs_per_image = 0;
-    if (lcm_conv_halo_launch(hp, B, (hipStream_t)stream, slabs_per_image) != 0) {
+    const int hrc = lcm_conv_halo_launch(hp, B, (hipStream_t)stream, slabs_per_image);
+    if (hrc < 0) return hrc;
+    if (hrc != 0) {
         lcm_set_error("conv3x3_gn: no tile configuration for B=%d %dx%d Cin=%d Cout=%d", B, hp.H, hp.W, Cin, Cout);
         return LCM_EINVAL;
     }
@@ -730,7 +793,7 @@ extern "C" int lcm_conv3x3_f16(const void* in, const void* W, const void* bias,
     LCM_REQUIRE(stride == 1 || stride == 2, "conv3x3: stride %d", stride);
     LCM_REQUIRE(!(ups && stride != 1), "conv3x3: upsample needs stride 1");
     if (rowadd) LCM_REQUIRE(ld_rowadd % 4 == 0, "conv3x3: ld_rowadd misaligned");
-    if (stride == 1 && (g_conv_impl == 1 || ups == 2))
+    if (stride == 1 && (g_conv_impl == 1 || (ups & 3) == 2 || (ups & 12)))
         return lcm_conv3x3_gn_f16(in, Cin, nullptr, 0, nullptr, nullptr, 0, W, bias, rowadd, ld_rowadd, res, out, B, Hin, Win,
                                   Cout, ups, stats_out, slabs_per_image, stream);
     const int Hl = ups ? 2 * Hin : Hin, Wl = ups ? 2 * Win : Win;
@@ -743,5 +806,5 @@ extern "C" int lcm_conv3x3_f16(const void* in, const void* W, const void* bias,
     p.ldo = Cout; p.ldr = Cout; p.ld_rowadd = ld_rowadd; p.rows_per_batch = p.Hout * p.Wout;
     p.epi = 0; p.out_scale = 1.0f;
     p.stats = (float*)stats_out;
-    return launch_igemm<1>(p, 1, (hipStream_t)stream, p.Hout * p.Wout, slabs_per_image);
+    return launch_igemm<1>(p, 1, (hipStream_t)stream, p.Hout * p.Wout, true, stats_out != nullptr, slabs_per_image);
 }

@@ -25,6 +25,7 @@ struct IgemmParams {
     float* stats;        // optional fused GroupNorm statistics of the OUTPUT: [slab][N][2] = per-channel (sum, sum of
                          // squares) of the fp16-rounded values each half-tile (or reduce slab) stores; null = off
     int reduce_rows;     // rows per workgroup of splitk_reduce_kernel
+    int img_rows;        // output rows per image (GEMM kinds; 0 = one image)
     int n_iters;         // igemm2: consecutive n-tiles one workgroup walks with a continuous LDS-DMA pipeline (>= 1)
 };
 
@@ -36,9 +37,13 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 template <int BM, int BN>
 __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f4 (&acc)[BN / 32][BM / 32], const int (&m_of)[BM / 32],
-                                               int n_wave, int fq, int z, int stats_slab = 0) {
+                                               int n_wave, int fq, int z, const int (&slab_of)[BM / 64]) {
     // m_of[b]: global output row of this lane in m-tile b, or -1 (outside the problem); n_wave: first channel of
-    // this wave's BN/2-wide slice.
+    // this wave's BN/2-wide slice.  slab_of[bp]: index of the CANONICAL statistics slab that the fragment pair
+    // (2bp, 2bp+1) of this wave covers (32 output pixels: 32 consecutive rows of a GEMM, a 2x16 / 4x8 pixel patch of a
+    // 3x3 convolution), or -1.  Slabs are a property of the output tensor, not of the tile shape: a 128-row tile emits
+    // two per wave, a 64-row tile one, with the same pixels and the same summation order inside each -- so the
+    // GroupNorm statistics (and everything downstream) do not depend on the launch plan or on the batch size.
     constexpr int TM = BM / 32, TN = BN / 32;
     if (p.splits > 1) {   // split-K: raw fp32 partial slab, epilogue runs in splitk_reduce_kernel
         float* __restrict__ wsb = p.ws + (long long)blockIdx.y * p.M * p.N;
@@ -67,45 +72,48 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f4 (&acc)[B
             const int n = n_wave + a * 16 + fq * 4;
             f4 bias4 = {0.f, 0.f, 0.f, 0.f};
             if (p.bias) { h4 t = *reinterpret_cast<const h4*>(p.bias + n); bias4 = (f4){(float)t[0], (float)t[1], (float)t[2], (float)t[3]}; }
-            float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int b = 0; b < TM; ++b) {
-                const int m = m_of[b];
-                if (m < 0) continue;
-                f4 v = acc[a][b];
-                v[0] += bias4[0]; v[1] += bias4[1]; v[2] += bias4[2]; v[3] += bias4[3];
-                if (p.rowadd) { h4 t = *reinterpret_cast<const h4*>(p.rowadd + (long long)(m / p.rows_per_batch) * p.ld_rowadd + n);
-                    v[0] += (float)t[0]; v[1] += (float)t[1]; v[2] += (float)t[2]; v[3] += (float)t[3]; }
-                v[0] *= p.out_scale; v[1] *= p.out_scale; v[2] *= p.out_scale; v[3] *= p.out_scale;
-                if (p.epi == 2) {          // quick_gelu: x * sigmoid(1.702 x)   (CLIP text encoder MLP)
+            for (int bp = 0; bp < TM / 2; ++bp) {
+                float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = v[j] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930157f * v[j]));
-                } else if (p.epi == 3) {   // exact gelu
+                for (int b = 2 * bp; b < 2 * bp + 2; ++b) {
+                    const int m = m_of[b];
+                    if (m < 0) continue;
+                    f4 v = acc[a][b];
+                    v[0] += bias4[0]; v[1] += bias4[1]; v[2] += bias4[2]; v[3] += bias4[3];
+                    if (p.rowadd) { h4 t = *reinterpret_cast<const h4*>(p.rowadd + (long long)(m / p.rows_per_batch) * p.ld_rowadd + n);
+                        v[0] += (float)t[0]; v[1] += (float)t[1]; v[2] += (float)t[2]; v[3] += (float)t[3]; }
+                    v[0] *= p.out_scale; v[1] *= p.out_scale; v[2] *= p.out_scale; v[3] *= p.out_scale;
+                    if (p.epi == 2) {          // quick_gelu: x * sigmoid(1.702 x)   (CLIP text encoder MLP)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = gelu_erf_f(v[j]);
-                }
-                if (p.res) { h4 t = *reinterpret_cast<const h4*>(p.res + (long long)m * p.ldr + n);
-                    v[0] += (float)t[0]; v[1] += (float)t[1]; v[2] += (float)t[2]; v[3] += (float)t[3]; }
-                h4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-                *reinterpret_cast<h4*>(outb + (long long)m * p.ldo + n) = o;
-                if (do_stats) {
+                        for (int j = 0; j < 4; ++j) v[j] = v[j] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930157f * v[j]));
+                    } else if (p.epi == 3) {   // exact gelu
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { const float f = (float)o[j]; ssum[j] += f; ssq[j] += f * f; }
-                }
-            }
-            if (do_stats) {   // fold the 16 pixel-lanes of the channel quad; one lane writes (sum, sumsq) x 4
+                        for (int j = 0; j < 4; ++j) v[j] = gelu_erf_f(v[j]);
+                    }
+                    if (p.res) { h4 t = *reinterpret_cast<const h4*>(p.res + (long long)m * p.ldr + n);
+                        v[0] += (float)t[0]; v[1] += (float)t[1]; v[2] += (float)t[2]; v[3] += (float)t[3]; }
+                    h4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                    *reinterpret_cast<h4*>(outb + (long long)m * p.ldo + n) = o;
+                    if (do_stats) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-#pragma unroll
-                    for (int o = 1; o < 16; o <<= 1) {
-                        ssum[j] += __shfl_xor(ssum[j], o, 64);
-                        ssq[j] += __shfl_xor(ssq[j], o, 64);
+                        for (int j = 0; j < 4; ++j) { const float f = (float)o[j]; ssum[j] += f; ssq[j] += f * f; }
                     }
                 }
-                if ((lane & 15) == 0) {
-                    float* dst = p.stats + ((long long)stats_slab * p.N + n) * 2;
-                    *reinterpret_cast<f4*>(dst) = (f4){ssum[0], ssq[0], ssum[1], ssq[1]};
-                    *reinterpret_cast<f4*>(dst + 4) = (f4){ssum[2], ssq[2], ssum[3], ssq[3]};
+                if (do_stats && slab_of[bp] >= 0) {   // fold the 16 pixel-lanes of the channel quad; one lane writes (sum, sumsq) x 4
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                        for (int o = 1; o < 16; o <<= 1) {
+                            ssum[j] += __shfl_xor(ssum[j], o, 64);
+                            ssq[j] += __shfl_xor(ssq[j], o, 64);
+                        }
+                    }
+                    if ((lane & 15) == 0) {
+                        float* dst = p.stats + ((long long)slab_of[bp] * p.N + n) * 2;
+                        *reinterpret_cast<f4*>(dst) = (f4){ssum[0], ssq[0], ssum[1], ssq[1]};
+                        *reinterpret_cast<f4*>(dst + 4) = (f4){ssum[2], ssq[2], ssum[3], ssq[3]};
+                    }
                 }
             }
         }

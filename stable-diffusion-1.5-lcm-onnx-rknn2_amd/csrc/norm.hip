@@ -290,8 +290,11 @@ __global__ __launch_bounds__(256) void gn_from_stats_fused_kernel(const half_t* 
 static long long g_gn_fused_bytes = 8ll << 20;   // tensors up to this size take the single-launch path above
 extern "C" int lcm_set_gn_fused_bytes(int64_t bytes) { g_gn_fused_bytes = bytes; return LCM_OK; }
 
+// rows per statistics chunk: a function of the image size only (never of the batch), so the partial sums -- and the
+// order they are folded in -- are the same for a request alone and inside a batch
 static inline int gn_rows(int B, int HW) {
-    long long r = ((long long)B * HW + 1023) / 1024;
+    (void)B;
+    long long r = ((long long)HW + 1023) / 1024;
     if (r < 16) r = 16;
     if (r > 4096) r = 4096;
     return (int)r;
@@ -449,38 +452,39 @@ extern "C" int lcm_layernorm_f16(const void* x, const void* gamma, const void* b
 }
 
 // ---------------------------------------------------------------------------------------------
-// Row softmax in place: one wave per row, n % 8 == 0, n <= 64*8*16 = 8192 per pass (looped).
+// Row softmax in place: one wave per row; any n <= ld, ld % 8 == 0.  The padding columns [n, ld) of each row are set
+// to zero (the AutoencoderKL attention pads S = h*w up to a multiple of 64 for the MFMA contractions around it).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void softmax_rows_kernel(half_t* __restrict__ x, int rows, int n, int ld) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     half_t* xr = x + (long long)row * ld;
-    const int ncc = n >> 3;
+    const int ncc = (n + 7) >> 3, nld = ld >> 3;
     float m = -3.0e38f;
     for (int cc = lane; cc < ncc; cc += 64) {
         h8 v = *reinterpret_cast<const h8*>(xr + cc * 8);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) m = fmaxf(m, (float)v[j]);
+        for (int j = 0; j < 8; ++j) if (cc * 8 + j < n) m = fmaxf(m, (float)v[j]);
     }
     m = wave_max(m);
     float s = 0.f;
     for (int cc = lane; cc < ncc; cc += 64) {
         h8 v = *reinterpret_cast<const h8*>(xr + cc * 8);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s += __expf((float)v[j] - m);
+        for (int j = 0; j < 8; ++j) if (cc * 8 + j < n) s += __expf((float)v[j] - m);
     }
     const float inv = 1.0f / wave_sum(s);
-    for (int cc = lane; cc < ncc; cc += 64) {
+    for (int cc = lane; cc < nld; cc += 64) {
         h8 v = *reinterpret_cast<const h8*>(xr + cc * 8);
         h8 o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (half_t)(__expf((float)v[j] - m) * inv);
+        for (int j = 0; j < 8; ++j) o[j] = (cc * 8 + j < n) ? (half_t)(__expf((float)v[j] - m) * inv) : (half_t)0;
         *reinterpret_cast<h8*>(xr + cc * 8) = o;
     }
 }
 
 extern "C" int lcm_softmax_rows_f16(void* x, int rows, int n, int ld, void* stream) {
-    LCM_REQUIRE(x && rows > 0 && n > 0 && n % 8 == 0 && ld % 8 == 0, "softmax: bad shape rows=%d n=%d ld=%d", rows, n, ld);
+    LCM_REQUIRE(x && rows > 0 && n > 0 && n <= ld && ld % 8 == 0, "softmax: bad shape rows=%d n=%d ld=%d", rows, n, ld);
     hipLaunchKernelGGL(softmax_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (half_t*)x, rows,
                        n, ld);
     LCM_CHECK_LAUNCH("softmax_rows");

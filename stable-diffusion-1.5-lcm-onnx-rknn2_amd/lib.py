@@ -32,7 +32,7 @@ _vp, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
 
 _SIGS = {
     "lcm_gemm_f16": [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _i,
-                     _i64, _i64, _i64, _vp, _i, C.POINTER(_i), _vp],
+                     _i64, _i64, _i64, _i, _vp, C.POINTER(_i), _vp],
     "lcm_conv3x3_f16": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, C.POINTER(_i), _vp],
     "lcm_groupnorm_from_stats_f16": [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp],
     "lcm_conv3x3_c4_f32in": [_vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
@@ -67,6 +67,7 @@ _SIGS = {
     "lcm_set_gn_fused_bytes": [_i64],
     "lcm_plan_set": [_i] * 9,
     "lcm_plan_clear": [],
+    "lcm_canonical_splits": [_i] * 6,
     "lcm_conv3x3_gn_f16": [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp,
                            C.POINTER(_i), _vp],
     "lcm_groupnorm_affine_f16": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp],
@@ -98,8 +99,43 @@ def load():
     lib.lcm_version.restype = _i
     lib.lcm_groupnorm_ws_bytes.restype = _i64
     lib.lcm_groupnorm_ws_bytes.argtypes = [_i, _i, _i, _i]
+    _install_plans(lib)
     _lib = lib
     return lib
+
+
+PACKAGED_PLANS = os.path.join(_HERE, "tuned_plans_gfx950.json")
+
+
+def read_plans(path) -> dict:
+    import json
+    try:
+        with open(path) as f:
+            return {tuple(int(v) for v in k.split(",")): tuple(val) for k, val in json.load(f).items()}
+    except Exception:
+        return {}
+
+
+def known_plans() -> dict:
+    """The launch-plan table known before any tuning launch: the one shipped with the package (tools/make_plans.py: the
+    standard SD1.5 / SDXL request shapes, tuned offline on an MI355X) overlaid by the user's LCM_TUNE_CACHE file.
+    LCM_TUNED_PLANS=0 ignores the shipped table."""
+    plans = {}
+    if os.environ.get("LCM_TUNED_PLANS", "1") != "0" and os.path.exists(PACKAGED_PLANS):
+        plans.update(read_plans(PACKAGED_PLANS))
+    p = os.environ.get("LCM_TUNE_CACHE", "")
+    if p and os.path.exists(p):
+        plans.update(read_plans(p))
+    return plans
+
+
+def _install_plans(lib):
+    """The WHOLE table goes into the library when it is loaded, not shape by shape as plans are built: a launch reads
+    its K partition from the entry of its per-image shape, which must not depend on which requests this process
+    happened to serve first (include/lcm_hip.h, Determinism)."""
+    for (kind, M, N, K, aux), val in known_plans().items():
+        bm, bn, sp, v = (int(x) for x in val[:4])
+        lib.lcm_plan_set(kind, M, N, K, aux, bm, bn, sp, v)
 
 
 def check(rc: int, what: str = ""):

@@ -44,11 +44,12 @@ class _Buffers:
         self.device = device
         self._b = {}
 
-    def get(self, role, *shape, dtype=torch.float16):
+    def get(self, role, *shape, dtype=torch.float16, zero=False):
+        """zero: zero-filled at allocation (buffers whose padding the kernels never write)."""
         key = (role, shape, dtype)
         t = self._b.get(key)
         if t is None:
-            t = torch.empty(shape, dtype=dtype, device=self.device)
+            t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
             self._b[key] = t
         return t
 
@@ -65,18 +66,17 @@ class _Net:
         self.device = device
         self.w = {}
         self.buf = _Buffers(device)
-        self._gn_ws = None
         self._stats = {}
 
     def _put(self, name, t, dtype=torch.float16):
         self.w[name] = _dev(t, self.device, dtype)
 
-    def stats(self, role, M, C):
-        """Per-role holder of the producer-written GroupNorm statistics of an [M, C] tensor."""
-        key = ("stats", role, M, C)
+    def stats(self, role, M, C, hw):
+        """Per-role holder of the producer-written GroupNorm statistics of an [M, C] tensor of M // hw images."""
+        key = ("stats", role, M, C, hw)
         st = self._stats.get(key)
         if st is None:
-            st = ops.Stats(torch.zeros(ops.stats_floats(M, C), dtype=torch.float32, device=self.device))
+            st = ops.Stats(torch.zeros(ops.stats_floats(M, C, hw), dtype=torch.float32, device=self.device))
             self._stats[key] = st
         return st
 
@@ -92,10 +92,15 @@ class _Net:
         return out
 
     def gn_ws(self, B, HW, C):
-        need = ops.groupnorm_ws_bytes(B, HW, C) // 4
-        if self._gn_ws is None or self._gn_ws.numel() < need:
-            self._gn_ws = torch.empty(max(need, 1 << 16), dtype=torch.float32, device=self.device)
-        return self._gn_ws
+        """fp32 scratch of the GroupNorm kernels (chunk partials + [B][C] scale / shift tables).  One tensor per
+        (B, HW, C), allocated once and never replaced: captured hipGraphs bake the raw pointer in, so growing a shared
+        buffer in place would leave earlier plans' graphs writing into freed memory."""
+        key = ("gn_ws", B, HW, C)
+        t = self._stats.get(key)
+        if t is None:
+            t = torch.empty(max(ops.groupnorm_ws_bytes(B, HW, C) // 4, 1024), dtype=torch.float32, device=self.device)
+            self._stats[key] = t
+        return t
 
     def weight_bytes(self):
         return sum(t.numel() * t.element_size() for t in self.w.values())
@@ -120,7 +125,7 @@ class _Net:
         w = self.w
         have1 = x_st is not None and x_st.P > 0 and (x2 is None or (x2_st is not None and x2_st.P > 0))
         h1 = self.buf.get("conv1", M, Cout)
-        h1_st = self.stats("conv1", M, Cout)
+        h1_st = self.stats("conv1", M, Cout, HW)
         if have1 and C1 % 64 == 0 and C2 % 64 == 0 and _fuse_gn_into_conv(M, Cin, Cout):
             sc_t, sh_t = ops.groupnorm_tables_from_stats(w[p + ".norm1.g"], w[p + ".norm1.b"], B, HW, C1, x_st, self.gn_ws(B, HW, Cin),
                                                          C2=C2, st2=x2_st if x2 is not None else None, eps=eps)
@@ -132,11 +137,11 @@ class _Net:
             ops.conv3x3(hn, w[p + ".conv1.w"], h1, B, H, W, Cin, Cout, bias=w[p + ".conv1.b"], rowadd=rowadd, stats=h1_st)
         if (p + ".sc.w") in w:
             sc = self.buf.get("shortcut", M, Cout)
-            ops.gemm(x, w[p + ".sc.w"], sc, bias=w[p + ".sc.b"], a2=x2)
+            ops.gemm(x, w[p + ".sc.w"], sc, bias=w[p + ".sc.b"], a2=x2, img_rows=HW)
         else:
             sc = x
         out = self.buf.get(out_role, M, Cout)
-        out_st = self.stats(out_role, M, Cout)
+        out_st = self.stats(out_role, M, Cout, HW)
         if h1_st.P > 0 and _fuse_gn_into_conv(M, Cout, Cout):
             sc_t, sh_t = ops.groupnorm_tables_from_stats(w[p + ".norm2.g"], w[p + ".norm2.b"], B, HW, Cout, h1_st,
                                                          self.gn_ws(B, HW, Cout), eps=eps)
@@ -244,7 +249,7 @@ class UNetHip(_Net):
     def encode_context(self, ehs, B):
         """ehs: fp16 [B*77, ctx] -> kv_all [B*77, kv_total]."""
         kv = self.buf.get("kv_all", B * TEXT_SEQ_LEN, self.kv_total)
-        ops.gemm(ehs, self.w["kv_all.w"], kv)
+        ops.gemm(ehs, self.w["kv_all.w"], kv, img_rows=TEXT_SEQ_LEN)
         return kv
 
     # ---- per step: time embedding MLP + all time_emb_proj (depend on t and guidance only) ----
@@ -286,7 +291,7 @@ class UNetHip(_Net):
         hn = self.buf.get("gn", M, C)
         self.norm(x, w[p + ".norm.g"], w[p + ".norm.b"], hn, B, HW, C, x_st=x_st, eps=1e-6, silu=False)
         h = self.buf.get("tf_h", M, C)
-        ops.gemm(hn, w[p + ".proj_in.w"], h, bias=w[p + ".proj_in.b"])
+        ops.gemm(hn, w[p + ".proj_in.w"], h, bias=w[p + ".proj_in.b"], img_rows=HW)
         n = self.buf.get("tf_ln", M, C)
         qkv = self.buf.get("tf_qkv", M, 3 * C)
         a = self.buf.get("tf_attn", M, C)
@@ -295,22 +300,22 @@ class UNetHip(_Net):
         for k in range(depth):
             q = f"{p}.{k}"
             ops.layernorm(h, w[q + ".norm1.g"], w[q + ".norm1.b"], n, M, C)
-            ops.gemm(n, w[q + ".qkv.w"], qkv)
+            ops.gemm(n, w[q + ".qkv.w"], qkv, img_rows=HW)
             ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], a, B, heads, HW, HW, d, ldq=3 * C, ldk=3 * C,
                           ldv=3 * C, ldo=C)
-            ops.gemm(a, w[q + ".o1.w"], h, bias=w[q + ".o1.b"], res=h)
+            ops.gemm(a, w[q + ".o1.w"], h, bias=w[q + ".o1.b"], res=h, img_rows=HW)
             ops.layernorm(h, w[q + ".norm2.g"], w[q + ".norm2.b"], n, M, C)
-            ops.gemm(n, w[q + ".q2.w"], q2)
+            ops.gemm(n, w[q + ".q2.w"], q2, img_rows=HW)
             off, _ = self.kv_off[q]
             ops.attention(q2, kv_all[:, off:off + C], kv_all[:, off + C:off + 2 * C], a, B, heads, HW, TEXT_SEQ_LEN, d,
                           ldq=C, ldk=self.kv_total, ldv=self.kv_total, ldo=C)
-            ops.gemm(a, w[q + ".o2.w"], h, bias=w[q + ".o2.b"], res=h)
+            ops.gemm(a, w[q + ".o2.w"], h, bias=w[q + ".o2.b"], res=h, img_rows=HW)
             ops.layernorm(h, w[q + ".norm3.g"], w[q + ".norm3.b"], n, M, C)
-            ops.gemm(n, w[q + ".ff1.w"], ff, bias=w[q + ".ff1.b"], epilogue=1)
-            ops.gemm(ff, w[q + ".ff2.w"], h, bias=w[q + ".ff2.b"], res=h)
+            ops.gemm(n, w[q + ".ff1.w"], ff, bias=w[q + ".ff1.b"], epilogue=1, img_rows=HW)
+            ops.gemm(ff, w[q + ".ff2.w"], h, bias=w[q + ".ff2.b"], res=h, img_rows=HW)
         out = self.buf.get(out_role, M, C)
-        out_st = self.stats(out_role, M, C)
-        ops.gemm(h, w[p + ".proj_out.w"], out, bias=w[p + ".proj_out.b"], res=x, stats=out_st, stats_hw=HW)
+        out_st = self.stats(out_role, M, C, HW)
+        ops.gemm(h, w[p + ".proj_out.w"], out, bias=w[p + ".proj_out.b"], res=x, stats=out_st, img_rows=HW)
         return out, out_st
 
     def forward(self, lat, t, kv_all, wemb, B, h, w_, eps_out, taps=None, aug=None):
@@ -330,6 +335,7 @@ class UNetHip(_Net):
                 taps[name] = t_.reshape(B, H_, W_, C).permute(0, 3, 1, 2).float().cpu()
 
         tap("conv_in", x, ch, H, W)
+        sizes = [(H, W)]                      # spatial size per level: a stride-2, padding-1 conv gives ceil(n / 2)
         for i in range(nb):
             for j in range(cfg["layers_per_block"]):
                 p = f"down_blocks.{i}.resnets.{j}"
@@ -346,10 +352,12 @@ class UNetHip(_Net):
                 ns += 1
             if i < nb - 1:
                 p = f"down_blocks.{i}.downsamplers.0.conv"
-                y = self.buf.get(f"skip{ns}", B * (H // 2) * (W // 2), ch)
-                st = self.stats(f"skip{ns}", B * (H // 2) * (W // 2), ch)
+                H2, W2 = (H + 1) // 2, (W + 1) // 2
+                y = self.buf.get(f"skip{ns}", B * H2 * W2, ch)
+                st = self.stats(f"skip{ns}", B * H2 * W2, ch, H2 * W2)
                 ops.conv3x3(x, wt[p + ".w"], y, B, H, W, ch, ch, bias=wt[p + ".b"], stride=2, stats=st)
-                H, W, x = H // 2, W // 2, y
+                H, W, x = H2, W2, y
+                sizes.append((H, W))
                 skips.append((x, ch, st))
                 ns += 1
         x, st = self._res("mid_block.resnets.0", x, ch, ch, B, H, W, ta, x_st=st)
@@ -373,11 +381,15 @@ class UNetHip(_Net):
                                              depth=depth_at(cfg, nb - 1 - i))
                     tap(p, x, ch, H, W)
             if i < nb - 1:
+                # Upsample2D with output_size = the next skip's size (UNet2DConditionModel passes upsample_size whenever the
+                # sample is not a multiple of 2**num_upsamplers): 2H or 2H-1
                 p = f"up_blocks.{i}.upsamplers.0.conv"
-                y = self.buf.get("ups", B * 4 * H * W, ch)
-                st = self.stats("ups", B * 4 * H * W, ch)
-                ops.conv3x3(x, wt[p + ".w"], y, B, H, W, ch, ch, bias=wt[p + ".b"], ups=2 if UPS_PHASES else 1, stats=st)
-                H, W, x = 2 * H, 2 * W, y
+                Ho, Wo = sizes[nb - 2 - i]
+                y = self.buf.get("ups", B * Ho * Wo, ch)
+                st = self.stats("ups", B * Ho * Wo, ch, Ho * Wo)
+                ops.conv3x3(x, wt[p + ".w"], y, B, H, W, ch, ch, bias=wt[p + ".b"], ups=2 if UPS_PHASES else 1, stats=st,
+                            out_hw=(Ho, Wo))
+                H, W, x = Ho, Wo, y
                 tap(f"up_blocks.{i}.upsamplers.0", x, ch, H, W)
         hn = self.buf.get("gn", B * H * W, ch)
         self.norm(x, wt["conv_norm_out.g"], wt["conv_norm_out.b"], hn, B, H * W, ch, x_st=st, eps=cfg["norm_eps"])
@@ -457,20 +469,29 @@ class VAEDecoderHip(_Net):
         S, M = H * W, B * H * W
         hn = self.buf.get("gn", M, C)
         self.norm(x, w["attn.norm.g"], w["attn.norm.b"], hn, B, S, C, x_st=x_st, eps=1e-6, silu=False)
-        q, k, v = (self.buf.get(f"attn_{n}", M, C) for n in "qkv")
-        for n, t in (("to_q", q), ("to_k", k), ("to_v", v)):
-            ops.gemm(hn, w[f"attn.{n}.w"], t, bias=w[f"attn.{n}.b"])
-        sc = self.buf.get("attn_scores", B * S, S)
-        ops.gemm(q, k, sc, M=S, N=S, K=C, lda=C, ldo=S, batch=B, strideA=S * C, strideW=S * C, strideO=S * S,
+        # The S x S product runs on the MFMA GEMM (N and K multiples of 64): S is padded to Sp with zero key rows / zero
+        # V^T columns (allocated zero, never written), the softmax normalises over the S real keys and zeroes the padding.
+        Sp = -(-S // 64) * 64
+        q, v = self.buf.get("attn_q", M, C), self.buf.get("attn_v", M, C)
+        k = self.buf.get("attn_k", B * Sp, C, zero=True)
+        ops.gemm(hn, w["attn.to_q.w"], q, bias=w["attn.to_q.b"], img_rows=S)
+        ops.gemm(hn, w["attn.to_v.w"], v, bias=w["attn.to_v.b"], img_rows=S)
+        if Sp == S:
+            ops.gemm(hn, w["attn.to_k.w"], k, bias=w["attn.to_k.b"], img_rows=S)
+        else:
+            ops.gemm(hn, w["attn.to_k.w"], k, bias=w["attn.to_k.b"], M=S, N=C, K=C, lda=C, ldo=C, batch=B, strideA=S * C,
+                     strideW=0, strideO=Sp * C)
+        sc = self.buf.get("attn_scores", B * S, Sp)
+        ops.gemm(q, k, sc, M=S, N=Sp, K=C, lda=C, ldo=Sp, batch=B, strideA=S * C, strideW=Sp * C, strideO=S * Sp,
                  out_scale=C ** -0.5)
-        ops.softmax_rows(sc, B * S, S, S)
-        vt = self.buf.get("attn_vt", B * C, S)
-        ops.transpose(v, vt, S, C, ldi=C, ldo=S, batch=B, stride_in=S * C, stride_out=C * S)
+        ops.softmax_rows(sc, B * S, S, Sp)
+        vt = self.buf.get("attn_vt", B * C, Sp, zero=True)
+        ops.transpose(v, vt, S, C, ldi=C, ldo=Sp, batch=B, stride_in=S * C, stride_out=C * Sp)
         o = self.buf.get("attn_o", M, C)
-        ops.gemm(sc, vt, o, M=S, N=C, K=S, lda=S, ldo=C, batch=B, strideA=S * S, strideW=C * S, strideO=S * C)
+        ops.gemm(sc, vt, o, M=S, N=C, K=Sp, lda=Sp, ldo=C, batch=B, strideA=S * Sp, strideW=C * Sp, strideO=S * C)
         out = self.buf.get("res_out2", M, C)
-        out_st = self.stats("res_out2", M, C)
-        ops.gemm(o, w["attn.o.w"], out, bias=w["attn.o.b"], res=x, stats=out_st, stats_hw=S)
+        out_st = self.stats("res_out2", M, C, S)
+        ops.gemm(o, w["attn.o.w"], out, bias=w["attn.o.b"], res=x, stats=out_st, img_rows=S)
         return out, out_st
 
     def decode(self, lat, B, h, w_, rgb_out, img_f32=None, taps=None, use_tiling=True):
@@ -547,7 +568,7 @@ class VAEDecoderHip(_Net):
             if i < nb - 1:
                 p = f"decoder.up_blocks.{i}.upsamplers.0.conv"
                 y = self.buf.get("ups", B * 4 * H * W, ch)
-                st = self.stats("ups", B * 4 * H * W, ch)
+                st = self.stats("ups", B * 4 * H * W, ch, 4 * H * W)
                 ops.conv3x3(x, wt[p + ".w"], y, B, H, W, ch, ch, bias=wt[p + ".b"], ups=2 if UPS_PHASES else 1, stats=st)
                 H, W, x = 2 * H, 2 * W, y
                 tap(f"decoder.up_blocks.{i}.upsamplers.0", x, ch, H, W)

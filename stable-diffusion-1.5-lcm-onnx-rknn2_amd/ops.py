@@ -53,6 +53,20 @@ def plan_clear():
     _lib.check(_lib.load().lcm_plan_clear(), "lcm_plan_clear")
 
 
+def plan_reset():
+    """Back to the table the library is loaded with (shipped plans + LCM_TUNE_CACHE)."""
+    plan_clear()
+    _lib._install_plans(_lib.load())
+
+
+def canonical_splits(kind, m_img, N, K, aux=1, ph=0):
+    """The K partition the library runs a contraction of this PER-IMAGE shape with (include/lcm_hip.h, Determinism)."""
+    n = _lib.load().lcm_canonical_splits(int(kind), int(m_img), int(N), int(K), int(aux), int(ph))
+    if n < 0:
+        _lib.check(n, "lcm_canonical_splits")
+    return n
+
+
 def tile_config(M, N, batch=1):
     c = _lib.load().lcm_gemm_tile_config(int(M), int(N), int(batch))
     return f"{c // 1000}x{c % 1000}"
@@ -68,10 +82,20 @@ class Stats:
         self.P = 0
 
 
-def stats_floats(M, N):
-    """fp32 elements that always suffice for the fused statistics of an [M, N] output: slabs are >= 32 rows for the
-    tile epilogues (M/32 + padding patches) and at most max(M/32, 256) for a split-K reduce."""
-    return 2 * N * (max(M // 16, 256) + 64)
+def stats_floats(M, N, hw=None):
+    """fp32 elements that always suffice for the fused statistics of an [M, N] output made of M // hw images of hw rows
+    (hw None: one image).  Per image: canonical 32-pixel slabs (<= hw/16 incl. partial patches at the image border) or
+    split-K reduce slabs (<= 255, a function of hw); slab counts are per image because the slab structure must not
+    depend on the batch."""
+    hw = int(hw) if hw else int(M)
+    B = max(1, int(M) // max(1, hw))
+    return 2 * N * B * (max(hw // 16, 256) + 64)
+
+
+def _stats_check(stats, M, N, hw, what):
+    if stats is not None and stats.P * max(1, M // max(1, hw)) * N * 2 > stats.buf.numel():
+        raise _lib.LcmHipError(f"{what}: statistics buffer too small ({stats.buf.numel()} floats for {stats.P} slabs x "
+                               f"{M // max(1, hw)} images x {N} channels): size it with ops.stats_floats(M, N, hw)")
 
 
 def _stats_args(stats):
@@ -82,9 +106,11 @@ def _stats_args(stats):
 
 
 def gemm(a, w, out, *, bias=None, res=None, rowadd=None, rows_per_batch=0, a2=None, epilogue=0, out_scale=1.0,
-         M=None, N=None, K=None, lda=None, ldo=None, batch=1, strideA=0, strideW=0, strideO=0, stats=None, stats_hw=0):
+         M=None, N=None, K=None, lda=None, ldo=None, batch=1, strideA=0, strideW=0, strideO=0, stats=None, img_rows=0):
     """out[m][n] = out_scale * sum_k [a|a2][m][k] w[n][k] + bias + rowadd + res  (see include/lcm_hip.h).
-    stats: optional ``Stats`` to receive the fused GroupNorm statistics of ``out`` (stats.P == 0 afterwards: not produced)."""
+    img_rows: rows per image when the M rows stack independent requests (keys the K partition: results are per-request
+    bit-identical at any batch size).  stats: optional ``Stats`` to receive the fused GroupNorm statistics of ``out``
+    (stats.P == 0 afterwards: not produced)."""
     L = _lib.load()
     sbuf, sp = _stats_args(stats)
     M = a.shape[0] if M is None else M
@@ -96,41 +122,52 @@ def gemm(a, w, out, *, bias=None, res=None, rowadd=None, rows_per_batch=0, a2=No
     if RECORD is not None:
         kw = dict(bias=bias, res=res, rowadd=rowadd, rows_per_batch=rows_per_batch, a2=a2, epilogue=epilogue,
                   out_scale=out_scale, M=M, N=N, K=K, lda=lda, ldo=ldo, batch=batch, strideA=strideA, strideW=strideW,
-                  strideO=strideO, stats=stats, stats_hw=stats_hw)
-        RECORD.append(((0, M, N, K, batch), dict(splittable=(epilogue == 0 and batch == 1), halo=False, geglu=(epilogue == 1)),
+                  strideO=strideO, stats=stats, img_rows=img_rows)
+        RECORD.append(((0, M, N, K, batch), dict(halo=False, geglu=(epilogue == 1), m_img=(img_rows if img_rows and M % img_rows == 0 else M),
+                                                 splittable=(epilogue == 0 and batch == 1 and not (strideA or strideW or strideO))),
                        lambda: gemm(a, w, out, **kw)))
     with _Timed("gemm", tile_config(M, N, batch) if PROFILE is not None else "", 2.0 * M * N * K * batch,
                 2.0 * batch * (M * K + N * K + M * N)):
         rc = L.lcm_gemm_f16(_p(a), lda, _p(a2), a2.stride(0) if a2 is not None else 0, K1, _p(w), _p(bias), _p(rowadd),
                             rowadd.stride(0) if rowadd is not None else 0, rows_per_batch,
                             _p(res), res.stride(0) if res is not None else 0, _p(out), ldo,
-                            M, N, K, epilogue, float(out_scale), batch, strideA, strideW, strideO,
-                            sbuf, stats_hw, C.byref(sp) if sp is not None else None, _stream())
+                            M, N, K, epilogue, float(out_scale), batch, strideA, strideW, strideO, int(img_rows),
+                            sbuf, C.byref(sp) if sp is not None else None, _stream())
     if stats is not None:
         stats.P = sp.value
     _lib.check(rc, "lcm_gemm_f16")
+    _stats_check(stats, M, N, img_rows if img_rows and M % img_rows == 0 else M, "gemm")
     return out
 
 
-def conv3x3(x, w, out, B, H, W, Cin, Cout, *, bias=None, rowadd=None, res=None, stride=1, ups=0, stats=None):
+def conv3x3(x, w, out, B, H, W, Cin, Cout, *, bias=None, rowadd=None, res=None, stride=1, ups=0, stats=None, out_hw=None):
+    """out_hw: (Ho, Wo) of an upsampling conv whose target is the odd-sized skip tensor (2H-1 / 2W-1): Upsample2D called
+    with output_size, F.interpolate(size=..., mode="nearest") == the 2x result cropped by one row / column."""
     L = _lib.load()
     sbuf, sp = _stats_args(stats)
     Ho, Wo = ((2 * H, 2 * W) if ups else ((H + 1) // 2, (W + 1) // 2) if stride == 2 else (H, W))
+    flags = ups
+    if out_hw is not None and tuple(out_hw) != (Ho, Wo):
+        if not ups or out_hw[0] not in (2 * H, 2 * H - 1) or out_hw[1] not in (2 * W, 2 * W - 1):
+            raise _lib.LcmHipError(f"conv3x3: output size {tuple(out_hw)} is not reachable from {H}x{W} (ups={ups})")
+        flags = ups | (4 if out_hw[0] == 2 * H - 1 else 0) | (8 if out_hw[1] == 2 * W - 1 else 0)
+        Ho, Wo = out_hw
     Mo = B * Ho * Wo
     taps = 4 if ups == 2 else 9                 # ups=2: phase-packed weights (packing.pack_conv3x3_up2), 4 taps per output
     if RECORD is not None:
-        kw = dict(bias=bias, rowadd=rowadd, res=res, stride=stride, ups=ups, stats=stats)
+        kw = dict(bias=bias, rowadd=rowadd, res=res, stride=stride, ups=ups, stats=stats, out_hw=out_hw)
         key = (1, Mo, Cout, 9 * Cin, 1) if stride == 2 else (2, Mo, Cout, taps * Cin, (Wo << 1))
-        RECORD.append((key, dict(splittable=True, halo=stride == 1, W=(W if ups == 2 else Wo), phases=4 if ups == 2 else 1),
+        RECORD.append((key, dict(halo=stride == 1, W=(W if ups == 2 else Wo), phases=4 if ups == 2 else 1, m_img=Mo // B, splittable=True),
                        lambda: conv3x3(x, w, out, B, H, W, Cin, Cout, **kw)))
     with _Timed("conv3x3", tile_config(Mo, Cout) if PROFILE is not None else "", 2.0 * Mo * Cout * taps * Cin,
                 2.0 * (B * H * W * Cin + 9 * Cin * Cout + Mo * Cout)):
         rc = L.lcm_conv3x3_f16(_p(x), _p(w), _p(bias), _p(rowadd), rowadd.stride(0) if rowadd is not None else 0,
-                               _p(res), _p(out), B, H, W, Cin, Cout, stride, ups, sbuf,
+                               _p(res), _p(out), B, H, W, Cin, Cout, stride, flags, sbuf,
                                C.byref(sp) if sp is not None else None, _stream())
     if stats is not None:
         stats.P = sp.value
     _lib.check(rc, "lcm_conv3x3_f16")
+    _stats_check(stats, Mo, Cout, Ho * Wo, "conv3x3")
     return out
 
 
@@ -146,7 +183,7 @@ def conv3x3_gn(x, w, out, B, H, W, C1, Cout, *, x2=None, C2=0, gn_scale=None, gn
         kw = dict(x2=x2, C2=C2, gn_scale=gn_scale, gn_shift=gn_shift, silu=silu, bias=bias, rowadd=rowadd, res=res, ups=ups,
                   stats=stats)
         RECORD.append(((2, Mo, Cout, 9 * Cin, (Wo << 1) | (1 if gn_scale is not None else 0)),
-                       dict(splittable=True, halo=True, W=Wo), lambda: conv3x3_gn(x, w, out, B, H, W, C1, Cout, **kw)))
+                       dict(halo=True, W=Wo, m_img=Mo // B, splittable=True), lambda: conv3x3_gn(x, w, out, B, H, W, C1, Cout, **kw)))
     with _Timed("conv3x3", "halo", 2.0 * Mo * Cout * 9 * Cin, 2.0 * (B * H * W * Cin + 9 * Cin * Cout + Mo * Cout)):
         rc = L.lcm_conv3x3_gn_f16(_p(x), C1, _p(x2), C2 if x2 is not None else 0, _p(gn_scale), _p(gn_shift),
                                   1 if silu else 0, _p(w), _p(bias), _p(rowadd),
@@ -155,6 +192,7 @@ def conv3x3_gn(x, w, out, B, H, W, C1, Cout, *, x2=None, C2=0, gn_scale=None, gn
     if stats is not None:
         stats.P = sp.value
     _lib.check(rc, "lcm_conv3x3_gn_f16")
+    _stats_check(stats, Mo, Cout, Ho * Wo, "conv3x3_gn")
     return out
 
 

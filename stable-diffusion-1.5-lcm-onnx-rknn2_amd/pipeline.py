@@ -58,7 +58,9 @@ def _splitk_workspace(device):
     key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
     t = _WS.get(key)
     if t is None:
-        t = torch.empty(int(os.environ.get("LCM_SPLITK_WS_MB", "64")) << 18, dtype=torch.float32, device=device)
+        # sized for a batch of 8 at 512x512 / SDXL 1024x1024 batch 1 (fp32 [splits][M][N] of the largest split layer); a launch
+        # that needs more fails loudly (a silently smaller split factor would change the numbers)
+        t = torch.empty(int(os.environ.get("LCM_SPLITK_WS_MB", "384")) << 18, dtype=torch.float32, device=device)
         _WS[key] = t
     return t
 
@@ -207,8 +209,10 @@ class LcmHipPipeline:
         torch.cuda.set_device(self.device)        # the pool may call from a thread other than the constructing one
         pe = torch.as_tensor(prompt_embeds)
         B = pe.shape[0]
-        if width % 64 or height % 64 or width <= 0 or height <= 0:
-            raise LcmHipError(f"unsupported size {width}x{height}: the HIP backend needs multiples of 64")
+        if width % 8 or height % 8 or width <= 0 or height <= 0:
+            # what diffusers' check_inputs raises for the reference ("`height` and `width` have to be divisible by 8");
+            # backends/rknnlcm.py:380-381 has the same rule
+            raise LcmHipError(f"`height` and `width` have to be divisible by 8 but are {height} and {width}.")
         h, w = height // VAE_SCALE_FACTOR, width // VAE_SCALE_FACTOR
         steps = int(steps)
         has_cond = self.unet.has_cond

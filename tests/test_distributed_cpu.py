@@ -73,3 +73,20 @@ def test_shard_bounds_cover_everything():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_bench_gpus_flag_is_honoured():
+    """`python bench.py --gpus N` by hand must launch N ranks itself (fresh children via torch.distributed.run, the parent
+    never initialises the GPU); inside a torchrun environment it is a rank, and a WORLD_SIZE that disagrees with --gpus is an
+    error rather than a silently smaller run."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    cmd = bench.spawn_command(8, ["--gpus", "8", "--steps", "5"], {})
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "8", "--steps", "5"]
+    assert os.path.basename(cmd[cmd.index("--master-port") + 2]) == "bench.py"
+    assert bench.spawn_command(1, [], {}) is None
+    assert bench.spawn_command(2, ["--gpus", "2"], {"WORLD_SIZE": "2", "RANK": "0"}) is None
+    with pytest.raises(SystemExit, match="WORLD_SIZE=2"):
+        bench.spawn_command(8, ["--gpus", "8"], {"WORLD_SIZE": "2"})

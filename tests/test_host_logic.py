@@ -31,11 +31,11 @@ def test_abi_argument_validation_without_gpu():
     import ctypes as C
     from sdlcm_amd import lib
     L = lib.load()
-    rc = L.lcm_gemm_f16(None, 0, None, 0, 0, None, None, None, 0, 0, None, 0, None, 0, 1, 64, 64, 0, 1.0, 1, 0, 0, 0, None, 0, None, None)
+    rc = L.lcm_gemm_f16(None, 0, None, 0, 0, None, None, None, 0, 0, None, 0, None, 0, 1, 64, 64, 0, 1.0, 1, 0, 0, 0, 0, None, None, None)
     assert rc == -1 and b"null pointer" in L.lcm_last_error()
     buf = C.create_string_buffer(16)
     p = C.cast(buf, C.c_void_p)
-    rc = L.lcm_gemm_f16(p, 8, None, 0, 0, p, None, None, 0, 0, None, 0, p, 8, 4, 64, 100, 0, 1.0, 1, 0, 0, 0, None, 0, None, None)
+    rc = L.lcm_gemm_f16(p, 8, None, 0, 0, p, None, None, 0, 0, None, 0, p, 8, 4, 64, 100, 0, 1.0, 1, 0, 0, 0, 0, None, None, None)
     assert rc == -1 and b"multiple of 64" in L.lcm_last_error()
     rc = L.lcm_attention_f16(p, 8, p, 8, p, 8, p, 8, 1, 8, 4, 4, 48, 1.0, 0, None)
     assert rc == -1 and b"head_dim" in L.lcm_last_error()
@@ -294,17 +294,24 @@ def test_plan_table_sources_and_gn_fusion_rule(tmp_path, monkeypatch):
     assert not model._fuse_gn_into_conv(8 * 128 * 128, 512, 512)        # 4 n-tiles of 128: the transform would repeat 4x
 
 
-def test_bench_traffic_lookup_reads_committed_pmc_table():
-    """bench.py's roofline.traffic comes from profiles/r01_traffic.json (separate --pmc passes): 2 x FETCH_SIZE + WRITE_SIZE
-    in bytes for a profiled (kernel, batch), None -- never a guess -- for anything else."""
+def test_bench_traffic_lookup_reads_committed_pmc_table(tmp_path, capsys):
+    """bench.py's roofline.traffic comes from the committed PMC table (separate --pmc passes): 2 x FETCH_SIZE + WRITE_SIZE
+    in bytes for a profiled (kernel, batch); for anything else None WITH the reason (named in traffic_source and on
+    stderr) -- never a guess, never a silent null."""
     import importlib.util, json, os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    tab = json.load(open(os.path.join(root, "profiles", "r01_traffic.json")))["batch"]
-    name, e = next(iter(tab["1"].items()))
-    t, src = bench._pmc_traffic(name, 1)
-    assert t == int((2 * e["FETCH_SIZE"] + e["WRITE_SIZE"]) * 1024) and "x2" in src
-    assert bench._pmc_traffic("no_such_kernel<1>", 1) == (None, None)
-    assert bench._pmc_traffic(name, 3) == (None, None)
+    tabf = tmp_path / "traffic.json"
+    tabf.write_text(json.dumps({"batch": {"1": {"void k<1>(P)": {"FETCH_SIZE": 100.0, "WRITE_SIZE": 50.0, "n_FETCH_SIZE": 7}}}}))
+    bench.TRAFFIC_FILE = str(tabf)
+    t, src = bench._pmc_traffic("void k<1>(P)", 1)
+    assert t == int((2 * 100.0 + 50.0) * 1024) and "x2" in src
+    for args in (("no_such_kernel<1>", 1), ("void k<1>(P)", 3)):
+        t, src = bench._pmc_traffic(*args)
+        assert t is None and "absent" in src
+    assert "WARNING" in capsys.readouterr().err
+    bench.TRAFFIC_FILE = str(tmp_path / "missing.json")
+    t, src = bench._pmc_traffic("void k<1>(P)", 1)
+    assert t is None and "unreadable" in src

@@ -172,7 +172,7 @@ def test_fused_groupnorm_stats_from_conv(B, H, W, Cin, Cout, splitk, stride):
     Ho, Wo = ((H + 1) // 2, (W + 1) // 2) if stride == 2 else (H, W)
     HW = Ho * Wo
     out = torch.empty(B * HW, Cout, dtype=torch.float16, device=DEV)
-    st = ops.Stats(torch.zeros(ops.stats_floats(B * HW, Cout), dtype=torch.float32, device=DEV))
+    st = ops.Stats(torch.zeros(ops.stats_floats(B * HW, Cout, HW), dtype=torch.float32, device=DEV))
     skws = torch.empty(16 << 20, dtype=torch.float32, device=DEV)
     ops.set_workspace(skws if splitk else None)
     try:
@@ -197,7 +197,7 @@ def test_fused_groupnorm_stats_from_conv(B, H, W, Cin, Cout, splitk, stride):
             ops.set_gn_fused_bytes(8 << 20)
         assert torch.equal(ys[0], ys[1])                # same arithmetic, same order
     else:
-        assert HW % 64 != 0, "statistics should have been produced for this shape"
+        assert HW % 32 != 0, "statistics should have been produced for this shape"
 
 
 def test_fused_groupnorm_stats_concat_and_gemm():
@@ -209,12 +209,12 @@ def test_fused_groupnorm_stats_concat_and_gemm():
     w1 = rnd(C1, 640, seed=2, scale=640 ** -0.5).to(DEV)
     r1 = rnd(B * HW, C1, seed=3).to(DEV)
     x1 = torch.empty(B * HW, C1, dtype=torch.float16, device=DEV)
-    st1 = ops.Stats(torch.zeros(ops.stats_floats(B * HW, C1), dtype=torch.float32, device=DEV))
-    ops.gemm(a, w1, x1, res=r1, stats=st1, stats_hw=HW)
+    st1 = ops.Stats(torch.zeros(ops.stats_floats(B * HW, C1, HW), dtype=torch.float32, device=DEV))
+    ops.gemm(a, w1, x1, res=r1, stats=st1, img_rows=HW)
     xin = to_nhwc(rnd(B, 320, H, W, seed=4)).to(DEV)
     w2 = pack3x3(rnd(C2, 320, 3, 3, seed=5, scale=(9 * 320) ** -0.5)).to(DEV)
     x2 = torch.empty(B * HW, C2, dtype=torch.float16, device=DEV)
-    st2 = ops.Stats(torch.zeros(ops.stats_floats(B * HW, C2), dtype=torch.float32, device=DEV))
+    st2 = ops.Stats(torch.zeros(ops.stats_floats(B * HW, C2, HW), dtype=torch.float32, device=DEV))
     ops.conv3x3(xin, w2, x2, B, H, W, 320, C2, stats=st2)
     torch.cuda.synchronize()
     assert st1.P > 0 and st2.P > 0
@@ -273,7 +273,7 @@ def test_conv_halo_pipelined_variant_is_bit_identical(B, H, W, Cin, Cout, ups, s
                 pair.append(o)
             torch.cuda.synchronize()
         finally:
-            ops.plan_clear()
+            ops.plan_reset()
             ops.set_workspace(None)
         assert torch.equal(pair[0], pair[1]), f"row-step variant differs at tile {bm}x{bn}"
     xin = from_nhwc(x.cpu().float(), B, H, W)
@@ -303,7 +303,7 @@ def test_conv_upsample_phase_decomposition(B, H, W, Cin, Cout, splitk):
         for thr in (0, 1 << 30):
             ops.set_halo_pipe_threshold(thr)
             o = torch.empty(B * Ho * Wo, Cout, dtype=torch.float16, device=DEV)
-            st = ops.Stats(torch.zeros(ops.stats_floats(B * Ho * Wo, Cout), dtype=torch.float32, device=DEV))
+            st = ops.Stats(torch.zeros(ops.stats_floats(B * Ho * Wo, Cout, Ho * Wo), dtype=torch.float32, device=DEV))
             ops.conv3x3(x, wp, o, B, H, W, Cin, Cout, bias=b, ups=2, stats=st)
             outs.append(o)
             sts.append(st)
@@ -323,7 +323,7 @@ def test_conv_upsample_phase_decomposition(B, H, W, Cin, Cout, splitk):
                 pair.append(o)
             torch.cuda.synchronize()
         finally:
-            ops.plan_clear()
+            ops.plan_reset()
         assert torch.equal(pair[0], pair[1])
         close(pair[1], outs[0], what="row-step phase conv vs default plan")
     xin = F.interpolate(from_nhwc(x.cpu().float(), B, H, W), scale_factor=2.0, mode="nearest")
@@ -352,9 +352,9 @@ def test_160_wide_tiles_gemm_and_conv(variant):
             ops.plan_set(0, M, N, K, 1, bm, 160, sp)
             a, w, b, r = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3), rnd(M, N, seed=4)
             out = torch.empty(M, N, dtype=torch.float16, device=DEV)
-            st = ops.Stats(torch.zeros(ops.stats_floats(M, N), dtype=torch.float32, device=DEV))
             hw = 256 if M % 256 == 0 else 0
-            ops.gemm(a.to(DEV), w.to(DEV), out, bias=b.to(DEV), res=r.to(DEV), stats=st if hw else None, stats_hw=hw)
+            st = ops.Stats(torch.zeros(ops.stats_floats(M, N, hw), dtype=torch.float32, device=DEV))
+            ops.gemm(a.to(DEV), w.to(DEV), out, bias=b.to(DEV), res=r.to(DEV), stats=st if hw else None, img_rows=hw)
             close(out, F.linear(a.float(), w.float(), b.float()) + r.float(), what=f"gemm 160-wide {M}x{N}x{K}")
             if hw and N % 32 == 0 and st.P > 0:
                 Bimg = M // hw
@@ -381,7 +381,7 @@ def test_160_wide_tiles_gemm_and_conv(variant):
                 xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
             close(from_nhwc(o, B, Ho, Wo), F.conv2d(xin, w4.float(), b.cpu().float(), padding=1), what=f"conv 160-wide {H}x{W} {Cin}->{Cout} ups={ups}")
     finally:
-        ops.plan_clear()
+        ops.plan_reset()
         ops.set_kernel_variant(-1)
         ops.set_halo_pipe_threshold(768)
         ops.set_workspace(None)
@@ -479,8 +479,8 @@ def test_gemm_persistent_over_n_is_bit_identical(M, N, K, epi):
         for on in (0, 1):
             ops.set_persist_n(on)
             o = torch.empty(M, N // 2 if epi == 1 else N, dtype=torch.float16, device=DEV)
-            st = ops.Stats(torch.zeros(ops.stats_floats(M, N), dtype=torch.float32, device=DEV)) if epi == 0 else None
-            ops.gemm(a, w, o, bias=b, res=res, epilogue=epi, stats=st, stats_hw=4096 if M % 4096 == 0 else 0)
+            st = ops.Stats(torch.zeros(ops.stats_floats(M, N, 4096 if M % 4096 == 0 else 0), dtype=torch.float32, device=DEV)) if epi == 0 else None
+            ops.gemm(a, w, o, bias=b, res=res, epilogue=epi, stats=st, img_rows=4096 if M % 4096 == 0 else 0)
             outs.append((o, st.buf.clone() if st is not None else None, st.P if st is not None else 0))
         torch.cuda.synchronize()
     finally:
@@ -675,3 +675,184 @@ def test_timestep_embedding_and_step_and_pool():
         ops.latents_pool8(lt.to(DEV), o, 1, hh, ww)
         assert o.cpu().numpy().tobytes() == glue.latents_blob(lt.numpy()) or \
             np.abs(o.cpu().float().numpy() - np.frombuffer(glue.latents_blob(lt.numpy()), np.float16).reshape(1, 4, 8, 8).astype(np.float32)).max() < 2e-3
+
+
+# ----------------------------------------------------------------------------------------------
+# Determinism (include/lcm_hip.h): results are a function of the per-image problem only.
+# ----------------------------------------------------------------------------------------------
+def _gn_of(out, st, B, HW, C):
+    gamma, beta = (1 + 0.1 * rnd(C, seed=4).float()).half().to(DEV), rnd(C, seed=5, scale=0.1).to(DEV)
+    y = torch.empty_like(out)
+    ws = torch.empty(ops.groupnorm_ws_bytes(B, HW, C) // 4 + 16, dtype=torch.float32, device=DEV)
+    ops.groupnorm_from_stats(out, gamma, beta, y, B, HW, C, st, ws)
+    return y
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,ups", [(1, 32, 32, 320, 640, 0), (2, 16, 16, 640, 640, 0), (1, 24, 24, 320, 320, 0),
+                                               (1, 16, 16, 640, 640, 2), (1, 12, 12, 128, 128, 0), (1, 64, 64, 128, 128, 0)])
+def test_conv_results_do_not_depend_on_tile_or_variant(B, H, W, Cin, Cout, ups):
+    """Every (tile, pipeline variant) the autotuner may pick for a 3x3 convolution gives the same output bits, the same
+    statistics slabs (count, layout, values) and hence the same GroupNorm downstream: plans are launch parameters."""
+    from sdlcm_amd.packing import pack_conv3x3_up2
+    x = to_nhwc(rnd(B, Cin, H, W, seed=1)).to(DEV)
+    w4 = rnd(Cout, Cin, 3, 3, seed=2, scale=(9 * Cin) ** -0.5)
+    w = (pack_conv3x3_up2(w4) if ups == 2 else pack3x3(w4)).to(DEV)
+    b = rnd(Cout, seed=3).to(DEV)
+    Ho, Wo = (2 * H, 2 * W) if ups else (H, W)
+    M, K = B * Ho * Wo, (4 if ups == 2 else 9) * Cin
+    skws = torch.empty(16 << 20, dtype=torch.float32, device=DEV)
+    ops.set_workspace(skws)
+    seen = []
+    try:
+        for bm in (128, 64):
+            for bn in (160, 128, 64):
+                if Cout % bn or (bm == 128 and not (W % 16 == 0 or W > 16)):
+                    continue
+                for var in (1, 2, 3) if bn <= 128 else (1, 2):
+                    ops.plan_clear()
+                    sp = ops.canonical_splits(2, M // B, Cout, K, Wo << 1, 1 if ups == 2 else 0)
+                    ops.plan_set(2, M, Cout, K, Wo << 1, bm, bn, ops.canonical_splits(2, M, Cout, K, Wo << 1, 1 if ups == 2 else 0), var)
+                    assert ops.canonical_splits(2, M // B, Cout, K, Wo << 1, 1 if ups == 2 else 0) == sp
+                    o = torch.empty(M, Cout, dtype=torch.float16, device=DEV)
+                    st = ops.Stats(torch.zeros(ops.stats_floats(M, Cout, Ho * Wo), dtype=torch.float32, device=DEV))
+                    ops.conv3x3(x, w, o, B, H, W, Cin, Cout, bias=b, ups=ups, stats=st)
+                    assert st.P > 0
+                    seen.append(((bm, bn, var), o, st.P, st.buf[:B * st.P * Cout * 2].clone(), _gn_of(o, st, B, Ho * Wo, Cout)))
+        torch.cuda.synchronize()
+    finally:
+        ops.plan_reset()
+        ops.set_workspace(None)
+    assert len(seen) >= 3
+    for tag, o, P, sb, y in seen[1:]:
+        assert P == seen[0][2], (tag, P, seen[0][2])
+        assert torch.equal(o, seen[0][1]), f"output differs under plan {tag}"
+        assert torch.equal(sb, seen[0][3]), f"statistics slabs differ under plan {tag}"
+        assert torch.equal(y, seen[0][4]), f"GroupNorm differs under plan {tag}"
+
+
+@pytest.mark.parametrize("M,N,K,hw", [(4096, 320, 320, 4096), (2048, 640, 1280, 1024), (512, 1280, 1280, 256), (1152, 320, 640, 576)])
+def test_gemm_results_do_not_depend_on_tile_or_variant(M, N, K, hw):
+    a, w, b = rnd(M, K, seed=1).to(DEV), rnd(N, K, seed=2, scale=K ** -0.5).to(DEV), rnd(N, seed=3).to(DEV)
+    res = rnd(M, N, seed=4).to(DEV)
+    skws = torch.empty(16 << 20, dtype=torch.float32, device=DEV)
+    ops.set_workspace(skws)
+    seen = []
+    try:
+        for bm in (128, 64):
+            for bn in (160, 128, 64):
+                if N % bn:
+                    continue
+                for var in (-1, 0, 1, 2, 4):
+                    ops.plan_clear()
+                    ops.plan_set(0, M, N, K, 1, bm, bn, ops.canonical_splits(0, M, N, K), var)
+                    o = torch.empty(M, N, dtype=torch.float16, device=DEV)
+                    st = ops.Stats(torch.zeros(ops.stats_floats(M, N, hw), dtype=torch.float32, device=DEV))
+                    ops.gemm(a, w, o, bias=b, res=res, stats=st, img_rows=hw)
+                    assert st.P == hw // 32 or ops.canonical_splits(0, hw, N, K) > 1
+                    seen.append(((bm, bn, var), o, st.P, st.buf[:(M // hw) * st.P * N * 2].clone(), _gn_of(o, st, M // hw, hw, N)))
+        torch.cuda.synchronize()
+    finally:
+        ops.plan_reset()
+        ops.set_workspace(None)
+    for tag, o, P, sb, y in seen[1:]:
+        assert P == seen[0][2]
+        assert torch.equal(o, seen[0][1]), f"output differs under plan {tag}"
+        assert torch.equal(sb, seen[0][3]), f"statistics slabs differ under plan {tag}"
+        assert torch.equal(y, seen[0][4]), f"GroupNorm differs under plan {tag}"
+    close(seen[0][1], F.linear(a.float().cpu(), w.float().cpu(), b.float().cpu()) + res.float().cpu(), what="gemm under plans")
+
+
+@pytest.mark.parametrize("H,W,Cin,Cout,stride,ups", [(8, 8, 1280, 1280, 1, 0), (16, 16, 640, 1280, 1, 0), (32, 32, 320, 640, 1, 0),
+                                                   (16, 16, 1280, 1280, 1, 2), (32, 32, 320, 320, 2, 0), (12, 20, 128, 128, 1, 0)])
+def test_contractions_are_batch_invariant(H, W, Cin, Cout, stride, ups):
+    """Image i of a batch of 3 gets exactly the bits it gets alone: the K partition (split-K included), the reduce slabs
+    and the statistics slabs are keyed on the per-image shape.  Covers halo conv (split and unsplit), the phase-decomposed
+    upsample conv, the stride-2 row-gather conv, and a GEMM with fused statistics on the conv output."""
+    from sdlcm_amd.packing import pack_conv3x3_up2
+    B = 3
+    xs = rnd(B, Cin, H, W, seed=1)
+    w4 = rnd(Cout, Cin, 3, 3, seed=2, scale=(9 * Cin) ** -0.5)
+    w = (pack_conv3x3_up2(w4) if ups == 2 else pack3x3(w4)).to(DEV)
+    wg = rnd(Cout, Cout, seed=6, scale=Cout ** -0.5).to(DEV)
+    b = rnd(Cout, seed=3).to(DEV)
+    Ho, Wo = (2 * H, 2 * W) if ups else ((H + 1) // 2, (W + 1) // 2) if stride == 2 else (H, W)
+    HW = Ho * Wo
+    skws = torch.empty(64 << 20, dtype=torch.float32, device=DEV)
+    ops.set_workspace(skws)
+
+    def run(x4):
+        n = x4.shape[0]
+        x = to_nhwc(x4).to(DEV)
+        o = torch.empty(n * HW, Cout, dtype=torch.float16, device=DEV)
+        st = ops.Stats(torch.zeros(ops.stats_floats(n * HW, Cout, HW), dtype=torch.float32, device=DEV))
+        ops.conv3x3(x, w, o, n, H, W, Cin, Cout, bias=b, stride=stride, ups=ups, stats=st)
+        y = _gn_of(o, st, n, HW, Cout) if st.P > 0 else o
+        o2 = torch.empty_like(o)
+        st2 = ops.Stats(torch.zeros(ops.stats_floats(n * HW, Cout, HW), dtype=torch.float32, device=DEV))
+        ops.gemm(y, wg, o2, res=o, stats=st2, img_rows=HW)
+        y2 = _gn_of(o2, st2, n, HW, Cout) if st2.P > 0 else o2
+        torch.cuda.synchronize()
+        return o.reshape(n, HW, Cout), st.P, y2.reshape(n, HW, Cout)
+    try:
+        ob, Pb, yb = run(xs)
+        for i in range(B):
+            o1, P1, y1 = run(xs[i:i + 1])
+            assert P1 == Pb
+            assert torch.equal(o1[0], ob[i]), f"conv output of image {i} depends on the batch"
+            assert torch.equal(y1[0], yb[i]), f"conv -> GroupNorm -> gemm -> GroupNorm of image {i} depends on the batch"
+    finally:
+        ops.set_workspace(None)
+
+
+def test_split_workspace_too_small_fails_loudly():
+    """A registered workspace that cannot hold the canonical partition is an error, never a silently different split."""
+    from sdlcm_amd.lib import LcmHipError
+    M, N, K = 64, 1280, 5120
+    assert ops.canonical_splits(0, M, N, K) > 1
+    a, w = rnd(M, K, seed=1).to(DEV), rnd(N, K, seed=2, scale=K ** -0.5).to(DEV)
+    out = torch.empty(M, N, dtype=torch.float16, device=DEV)
+    tiny = torch.empty(1024, dtype=torch.float32, device=DEV)
+    ops.set_workspace(tiny)
+    try:
+        with pytest.raises(LcmHipError, match="workspace too small"):
+            ops.gemm(a, w, out)
+    finally:
+        ops.set_workspace(None)
+
+
+# ----------------------------------------------------------------------------------------------
+# Request sizes that are multiples of 8 but not of 64 (backends/rknnlcm.py:380-381; the UI ships 640x360).
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,H,W,Cin,Cout,oh,ow,phase", [(1, 7, 12, 128, 128, 13, 24, True), (2, 13, 9, 64, 128, 25, 17, True),
+                                                      (1, 12, 23, 128, 64, 23, 45, True), (1, 7, 12, 128, 128, 13, 23, False),
+                                                      (1, 25, 33, 320, 320, 49, 65, True)])
+def test_conv_upsample_to_odd_skip_size(B, H, W, Cin, Cout, oh, ow, phase):
+    """Upsample2D with output_size = an odd-sized skip (2H-1 / 2W-1): F.interpolate(size=..., mode="nearest") -> conv3x3,
+    as the phase-decomposed conv (and the loader-fused form) with the last output row / column cropped; fused statistics
+    of the cropped output included."""
+    from sdlcm_amd.packing import pack_conv3x3_up2
+    x4 = rnd(B, Cin, H, W, seed=1)
+    w4 = rnd(Cout, Cin, 3, 3, seed=2, scale=(9 * Cin) ** -0.5)
+    b = rnd(Cout, seed=3)
+    ref = F.conv2d(F.interpolate(x4.float(), size=(oh, ow), mode="nearest"), w4.float(), b.float(), padding=1)
+    wk = (pack_conv3x3_up2(w4) if phase else pack3x3(w4)).to(DEV)
+    o = torch.empty(B * oh * ow, Cout, dtype=torch.float16, device=DEV)
+    st = ops.Stats(torch.zeros(ops.stats_floats(B * oh * ow, Cout, oh * ow), dtype=torch.float32, device=DEV))
+    ops.conv3x3(to_nhwc(x4).to(DEV), wk, o, B, H, W, Cin, Cout, bias=b.to(DEV), ups=2 if phase else 1, stats=st, out_hw=(oh, ow))
+    torch.cuda.synchronize()
+    close(from_nhwc(o, B, oh, ow), ref, what="upsample conv to odd size")
+    assert st.P > 0
+    gamma, beta = (1 + 0.1 * rnd(Cout, seed=4).float()).half(), rnd(Cout, seed=5, scale=0.1)
+    y = _gn_of(o, st, B, oh * ow, Cout)
+    close(y, _ref_gn(o.cpu(), B, oh * ow, Cout, gamma, beta, 1e-5, True), what="gn from the statistics of a cropped upsample conv")
+
+
+@pytest.mark.parametrize("rows,n,ld", [(37, 100, 128), (5, 3185, 3200), (64, 64, 64), (9, 7, 64)])
+def test_softmax_ragged_rows_zero_padding(rows, n, ld):
+    x = (rnd(rows, ld, seed=1) * 3).to(DEV)
+    ref = torch.softmax(x[:, :n].float().cpu(), dim=1)
+    ops.softmax_rows(x, rows, n, ld)
+    torch.cuda.synchronize()
+    got = x.float().cpu()
+    assert (got[:, n:] == 0).all()
+    assert (got[:, :n] - ref).abs().max() < 2e-3

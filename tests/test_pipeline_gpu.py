@@ -178,6 +178,27 @@ def test_non_square_768x512_parity(state):
     assert e.max() < 1e-2
 
 
+@pytest.mark.parametrize("width,height,steps", [(520, 392, 2), (360, 200, 1)])
+def test_sizes_multiple_of_8_parity(state, width, height, steps):
+    """Sizes the reference accepts (multiples of 8: backends/rknnlcm.py:380-381) that are not multiples of 64: odd latent
+    sides at every UNet level (65x49 -> 33x25 -> 17x13 -> 9x7), upsamplers target the odd-sized skips, ragged attention
+    sequences, GroupNorm statistics of images whose pixel count is not a multiple of 32, VAE attention with padded S."""
+    hip, ora = state["hip"], state["ora"]
+    pe = _embeds(1, seed=17)
+    ref = ora(pe.float(), width, height, steps, 1.0, 99)
+    out = hip.generate(pe, [99], width, height, steps, 1.0, want_float=True)
+    assert out["rgb"].shape == (1, height, width, 3)
+    _report(f"{width}x{height} latents", out["latents"], ref["latents"])
+    a = np.clip(out["image"].transpose(0, 3, 1, 2) / 2 + 0.5, 0, 1)
+    b = np.clip(ref["image"] / 2 + 0.5, 0, 1)
+    e = _report(f"{width}x{height} {steps}-step image[0,1]", a, b)
+    assert e.max() < 1e-2
+    rep = hip.generate(pe, [99], width, height, steps, 1.0)
+    assert np.array_equal(rep["rgb"], out["rgb"])
+    with pytest.raises(Exception, match="divisible by 8"):
+        hip.generate(pe, [99], 516, 392, 1, 1.0)
+
+
 def test_graph_replay_equals_eager_and_is_deterministic(state):
     hip = state["hip"]
     pe = _embeds(1, seed=9)
@@ -191,18 +212,20 @@ def test_graph_replay_equals_eager_and_is_deterministic(state):
     assert not np.array_equal(other["rgb"], g1["rgb"])
 
 
-def test_batched_requests_match_single_requests(state):
+@pytest.mark.parametrize("size,steps,B", [(128, 4, 3), (256, 2, 2), (512, 1, 2)])
+def test_batched_requests_match_single_requests(state, size, steps, B):
+    """A request inside a batch gets exactly the bytes it gets alone (the reference's same-seed contract,
+    tests/test_sdxl_worker.py:171-198, extended to micro-batches): K partitions, reduce slabs and statistics slabs are
+    keyed on the per-image shape.  512x512 at batch 2 also flips the VAE's 256^2 level from the separate GroupNorm-apply
+    pass to the form fused into the conv's halo staging -- same bits."""
     hip = state["hip"]
-    pe = _embeds(3, seed=21)
-    seeds = [1000, 1001, 1002]
-    batched = hip.generate(pe, seeds, 128, 128, 4, 1.0)
+    pe = _embeds(B, seed=21)
+    seeds = [1000 + i for i in range(B)]
+    batched = hip.generate(pe, seeds, size, size, steps, 1.0)
     for i, s in enumerate(seeds):
-        one = hip.generate(pe[i:i + 1], [s], 128, 128, 4, 1.0)
-        # split-K factors depend on the batch size, so the fp32 summation order (not the values summed) may
-        # differ between a batched and a single run: equal up to fp16 rounding, not necessarily bit for bit
-        d = np.abs(one["rgb"][0].astype(int) - batched["rgb"][i].astype(int))
-        assert d.max() <= 2 and (d > 0).mean() < 0.05, f"request {i} differs in the batch: max {d.max()}"
-        assert np.abs(one["latents"][0] - batched["latents"][i]).max() < 0.05
+        one = hip.generate(pe[i:i + 1], [s], size, size, steps, 1.0)
+        assert np.array_equal(one["latents"][0], batched["latents"][i]), f"latents of request {i} depend on the batch"
+        assert np.array_equal(one["rgb"][0], batched["rgb"][i]), f"pixels of request {i} depend on the batch"
 
 
 def test_latents_blob_matches_oracle_pooling(state):
@@ -213,18 +236,6 @@ def test_latents_blob_matches_oracle_pooling(state):
     assert len(blob) == 512
     ref = np.frombuffer(glue.latents_blob(out["latents"][:1]), np.float16)
     assert np.abs(np.frombuffer(blob, np.float16).astype(np.float32) - ref.astype(np.float32)).max() < 2e-2
-
-
-def test_full_size_parity_512(state):
-    """BASELINE config 2 shape: 512x512, 4 steps, batch 1 -- the north_star tolerance at full size."""
-    hip, ora = state["hip"], state["ora"]
-    pe = _embeds(1, seed=42)
-    ref = ora(pe.float(), 512, 512, 4, 1.0, 42)
-    out = hip.generate(pe, [42], 512, 512, 4, 1.0, want_float=True)
-    a = np.clip(out["image"].transpose(0, 3, 1, 2) / 2 + 0.5, 0, 1)
-    b = np.clip(ref["image"] / 2 + 0.5, 0, 1)
-    e = _report("512px 4-step image[0,1]", a, b)
-    assert e.max() < 1e-2
 
 
 @pytest.mark.parametrize("B,act", [(1, "quick_gelu"), (3, "quick_gelu"), (2, "gelu")])
@@ -325,8 +336,7 @@ def test_sdxl_style_pipeline_parity(guidance):
     g1 = hip.generate(pe, [21], 192, 128, 3, guidance, **kw)
     g2 = hip.generate(pe, [21], 192, 128, 3, guidance, **kw)
     assert np.array_equal(g1["rgb"], g2["rgb"])
-    d = np.abs(g1["rgb"].astype(int) - out["rgb"].astype(int))
-    assert d.max() <= 2            # graph (autotuned plans) vs the earlier eager pass: summation order only
+    assert np.array_equal(g1["rgb"], out["rgb"])      # graph (tuned launch plans) vs the earlier eager pass: plans never change bits
     hip.drop_plans()
 
 
