@@ -101,7 +101,7 @@ def roofline_leg(pipe, P, guidance, ms_per_step):
     table = {k: {"launches": v["n"], "bracketed_ms": round(v["ms"], 3), "bracketed_avg_us": round(v["ms"] * 1e3 / v["n"], 2),
                  "gflop": round(v["flops"] / 1e9, 1)} for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
     tot_f = sum(v["flops"] for v in agg.values())
-    traffic, traffic_src = _pmc_traffic(name, P.B)
+    traffic, traffic_src = _pmc_traffic(name.replace(" +splitk", ""), P.B)     # rocprof names carry no split suffix
     out = {"bound": "mfma", "kernel": f"{name} ({dom['kind']})",
             "achieved": round(ach, 1), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_F16_PEAK_TFLOPS, 4),
             "launches": dom["n"], "avg_launch_us": round(iso_ms * 1e3 / dom["n"], 2),
@@ -174,6 +174,8 @@ def main():
                     help="sd15 = BASELINE configs[1..3]; sdxl = configs[4] (SDXL-base 1024x1024, 30 steps, guidance 1.0, no CFG)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true",
+                    help="skip the roofline leg (profiling runs: the kernel trace then holds graph replays only, tools/pass_breakdown.py)")
     args = ap.parse_args()
 
     # N > 1 without a torchrun environment: become the launcher.  The parent never touches the GPU (no torch import, no
@@ -315,7 +317,7 @@ def main():
     if world > 1:
         line["exchange"] = {"what": f"broadcast of [{world * B},77,{D}] fp16 prompt embeddings from rank 0, before the timed region",
                             "backend": "rccl" if backend == "nccl" else backend, "ms": round(bcast_ms.get(B, 0.0), 3)}
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_roofline:
         line["roofline"] = roofline_leg(pipe, P, 1.0, dt / args.steps * 1e3)
         if args.model == "sdxl":
             fl_img = (6.761e12 * n + 10.470e12) * (S * S) / (1024 * 1024)

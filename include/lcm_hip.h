@@ -67,11 +67,18 @@ int lcm_gemm_f16(const void* A, int lda, const void* A2, int lda2, int K1,
  * silently run with fewer parts, because that would change the numbers.  bytes >= 4*splits*M*N of the largest split
  * layer (64 MiB covers SD1.5 at batch 1, 384 MiB batch 8). */
 int lcm_set_workspace(void* ptr, int64_t bytes);
+/* a workspace of its own for the launches of one stream (ptr NULL: forget it): two sampler passes in flight on two
+ * streams ("lanes") must not share split-K slabs.  Looked up before the device-wide workspace. */
+int lcm_set_stream_workspace(void* stream, void* ptr, int64_t bytes);
 
 /* launch heuristics of the contraction kernels (0 keeps a value): workgroups a split-K launch aims for, the
  * maximum number of K splits, and the workgroup count below which a larger tile is passed over.  These feed the
  * canonical-partition heuristic: changing them changes fp32 summation order for shapes without a plan entry. */
 int lcm_set_tuning(int target_wgs, int max_splits, int min_wgs);
+/* where the canonical K partition may have more than one part: images of at most `max_rows_per_image` output rows
+ * (default 1024), at most `max_parts` parts (default 4).  A deployment-wide constant: it is part of what decides the
+ * fp32 summation order. */
+int lcm_set_split_policy(int max_rows_per_image, int max_parts);
 
 /* Determinism.  The fp32 summation order of every output element is fixed by the K partition of its layer, and
  * that partition is a function of the PER-IMAGE problem only: (kind, rows per image, N, K[, output width]) ->
@@ -89,6 +96,20 @@ int lcm_plan_set(int kind, int M, int N, int K, int aux, int bm, int bn, int spl
 int lcm_plan_clear(void);
 /* the K partition a contraction of this per-image shape runs with (ph = 1: phase-decomposed upsample conv) */
 int lcm_canonical_splits(int kind, int m_img, int N, int K, int aux, int ph);
+
+/* ---- LayerNorm -> Linear as one contraction (BasicTransformerBlock: norm1 -> attn1.to_q|k|v, norm2 -> attn2.to_q,
+ * norm3 -> ff.net.0.proj) ----
+ *   LN(x) W^T + b  =  rstd[m] * (sum_k x[m][k] W'[n][k] - mean[m] * ln_g[n]) + ln_c[n]
+ * with W' = gamma (*) W in fp16, ln_g[n] = sum_k W'[n][k] and ln_c[n] = sum_k beta[k] W[n][k] + b[n] in fp32 (packed once
+ * by the host).  The row statistics (sum, sum of squares over K, fp32) are accumulated from the A fragments while the
+ * kernel walks K, so the normalisation costs no launch and no extra pass over the activations.  K is never split.
+ * epilogue: LCM_EPI_NONE or LCM_EPI_GEGLU (ln_g / ln_c in the packed row order of W).  img_rows as lcm_gemm_f16. */
+int lcm_gemm_ln_f16(const void* A, int lda, const void* W, const void* ln_g, const void* ln_c, float eps,
+                    void* out, int ldo, int M, int N, int K, int epilogue, int img_rows, void* stream);
+/* refresh ln_g (= row sums of the live fp16 W') and ln_c (= c_base + alpha * c_delta; c_out / c_delta may be NULL) after
+ * a style LoRA re-merged W' in place */
+int lcm_ln_fold_refresh(const void* W, int N, int K, const void* c_base, const void* c_delta, float alpha,
+                        void* g_out, void* c_out, void* stream);
 
 /* 1: short-K GEMM launches with more tiles than the chip holds let each workgroup walk several n-tiles with a
  * continuous LDS-DMA pipeline (no ramp / drain per tile); 0 (default): one tile per workgroup.  Bit-identical. */

@@ -29,8 +29,16 @@ class MicroBatcher:
     """
 
     def __init__(self, run_batch: Callable[[Hashable, list], list], max_batch: int = 8, window_ms: float = 0.0,
-                 sizes: Sequence[int] = (1, 2, 4, 8), name: str = "lcm-microbatch"):
+                 sizes: Sequence[int] = (1, 2, 4, 8), name: str = "lcm-microbatch", lanes: int = 1):
+        """lanes > 1: that many dispatcher threads pull from the one queue and call ``run_batch(key, items, lane)`` --
+        passes on different lanes overlap on the GPU (pipeline.LcmHipPipeline lanes); with lanes == 1 the callback keeps
+        its two-argument form."""
         self.run_batch = run_batch
+        self.lanes = max(1, int(lanes))
+        # Lanes beyond the first serve LOW load only: with up to `lane_max_waiting` jobs waiting a second pass in flight
+        # beats batching (two batch-1 passes overlap to ~1.4x the time of one), with more waiting the first lane's next
+        # batched pass is the better use of the GPU (batch 4 / 8 passes already fill it; two of them just share it)
+        self.lane_max_waiting = 2
         self.sizes = sorted(s for s in set(int(x) for x in sizes) if 1 <= s <= max(1, int(max_batch))) or [1]
         self.max_batch = self.sizes[-1]
         self.window = max(0.0, float(window_ms)) / 1e3
@@ -38,8 +46,9 @@ class MicroBatcher:
         self._cv = threading.Condition()
         self._closed = False
         self.batches: List[int] = []                # sizes of the batches run so far (telemetry / tests)
-        self._thread = threading.Thread(target=self._loop, name=name, daemon=True)
-        self._thread.start()
+        self._threads = [threading.Thread(target=self._loop, args=(i,), name=f"{name}-{i}", daemon=True) for i in range(self.lanes)]
+        for t in self._threads:
+            t.start()
 
     def submit(self, key: Hashable, item) -> Future:
         fut: Future = Future()
@@ -60,13 +69,16 @@ class MicroBatcher:
         self._q = deque(e for e in self._q if id(e) not in ids)
         return key, batch
 
-    def _loop(self):
+    def _loop(self, lane=0):
         while True:
             with self._cv:
                 while not self._q and not self._closed:
                     self._cv.wait()
                 if not self._q and self._closed:
                     return
+                if lane > 0 and len(self._q) > self.lane_max_waiting and not self._closed:
+                    self._cv.wait(0.002)            # high load: leave the queue to lane 0's next (larger) batch
+                    continue
                 if self.window > 0:
                     head_key, deadline = self._q[0][0], self._q[0][3] + self.window
                     while (sum(1 for e in self._q if e[0] == head_key) < self.max_batch and not self._closed):
@@ -77,7 +89,7 @@ class MicroBatcher:
                 key, batch = self._take()
             items = [e[1] for e in batch]
             try:
-                results = self.run_batch(key, items)
+                results = self.run_batch(key, items, lane) if self.lanes > 1 else self.run_batch(key, items)
                 if len(results) != len(items):
                     raise RuntimeError(f"run_batch returned {len(results)} results for {len(items)} items")
                 self.batches.append(len(items))
@@ -92,8 +104,9 @@ class MicroBatcher:
         with self._cv:
             self._closed = True
             self._cv.notify_all()
-        if threading.current_thread() is not self._thread:      # a finalizer may run on the dispatcher thread itself
-            self._thread.join(timeout)
+        for t in self._threads:
+            if threading.current_thread() is not t:             # a finalizer may run on a dispatcher thread itself
+                t.join(timeout)
         with self._cv:
             for e in self._q:
                 if not e[2].done():

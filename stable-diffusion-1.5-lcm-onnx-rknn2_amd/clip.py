@@ -114,6 +114,13 @@ class ClipTextHip:
     def weight_bytes(self):
         return sum(t.numel() * 2 for t in self.w.values())
 
+    def view(self):
+        """Same encoder (shared weights), own activation buffers: one per pipeline lane."""
+        v = object.__new__(type(self))
+        v.__dict__.update(self.__dict__)
+        v._buf = {}
+        return v
+
     @torch.inference_mode()
     def forward(self, ids: torch.Tensor, output="last", pooled=False):
         """ids: int [B, S<=77] (host or device).

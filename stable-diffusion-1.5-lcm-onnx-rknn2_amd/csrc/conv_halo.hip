@@ -217,8 +217,7 @@ __global__ __launch_bounds__(256, 3) void conv_halo_kernel(HaloParams hp) {
     for (int b = 0; b < TM; ++b) {
         const int q = (wm * TM + b) * 16 + frow;
         const int y = y0 + q / TW, x = x0 + q % TW;
-        if (PH) m_of[b] = (y < IH && x < IW && 2 * y + py < hp.H && 2 * x + px < hp.W) ? (bimg * hp.H + 2 * y + py) * hp.W + 2 * x + px : -1;
-        else m_of[b] = (y < IH && x < IW) ? (bimg * hp.H + y) * hp.W + x : -1;
+        m_of[b] = (y < IH && x < IW) ? (PH ? (bimg * hp.H + 2 * y + py) * hp.W + 2 * x + px : (bimg * hp.H + y) * hp.W + x) : -1;
     }
     int slab_of[BM / 64];
     halo_slabs<TH, TW, PH>(slab_of, wm, bimg, y0, x0, IH, IW, phase);
@@ -423,8 +422,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_pipe_kernel(HaloParams hp) {
     for (int b = 0; b < TM; ++b) {
         const int q = (wm * TM + b) * 16 + frow;
         const int y = y0 + q / TW, x = x0 + q % TW;
-        if (PH) m_of[b] = (y < IH && x < IW && 2 * y + py < hp.H && 2 * x + px < hp.W) ? (bimg * hp.H + 2 * y + py) * hp.W + 2 * x + px : -1;
-        else m_of[b] = (y < IH && x < IW) ? (bimg * hp.H + y) * hp.W + x : -1;
+        m_of[b] = (y < IH && x < IW) ? (PH ? (bimg * hp.H + 2 * y + py) * hp.W + 2 * x + px : (bimg * hp.H + y) * hp.W + x) : -1;
     }
     int slab_of[BM / 64];
     halo_slabs<TH, TW, PH>(slab_of, wm, bimg, y0, x0, IH, IW, phase);
@@ -434,8 +432,10 @@ __global__ __launch_bounds__(256, 2) void conv_halo_pipe_kernel(HaloParams hp) {
 // split-K combine kernel lives in igemm.hip
 extern void lcm_launch_splitk_reduce(IgemmParams& p, hipStream_t s);
 extern int lcm_reduce_rows(int hw);
-extern float* lcm_splitk_workspace(long long* bytes);
+extern int lcm_reduce_slabs(int hw);
+extern float* lcm_splitk_workspace(long long* bytes, hipStream_t s);
 extern void lcm_tuning(int* target_wgs, int* max_splits, int* min_wgs);
+extern int lcm_split_policy(int m_img, int sp);
 extern bool lcm_plan_get(int kind, int M, int N, int K, int aux, int* bm, int* bn, int* splits, int* variant);
 
 static int g_halo_pipe_below = 768;      // workgroup count under which the pipelined (WS=3) variant is used
@@ -528,10 +528,13 @@ static inline int halo_tw(int IW) { return (IW % 16 == 0 || IW > 16) ? 16 : 8; }
 int lcm_canonical_splits_halo(int m_img, int N, int K, int IH, int IW, int W, int ph, int xform) {      // W: output width
     const int nchunks = (K / (ph ? 4 : 9)) >> 6;
     int pbm, pbn, psp, pv;
-    int sp = lcm_plan_get(2, m_img, N, K, (W << 1) | (xform ? 1 : 0), &pbm, &pbn, &psp, &pv)
+    // one partition per layer shape: the GroupNorm-fused form of a conv (chosen from the TOTAL tensor size, i.e. from the
+    // batch) must produce the bits of the plain form, so both read the plain form's entry
+    (void)xform;
+    int sp = lcm_plan_get(2, m_img, N, K, W << 1, &pbm, &pbn, &psp, &pv)
                  ? psp : halo_pick(1, IH, IW, ph ? 4 : 1, halo_tw(IW), m_img, N, nchunks, -1).splits;
     if (sp > nchunks) sp = nchunks;
-    return sp < 1 ? 1 : sp;
+    return lcm_split_policy(m_img, sp);
 }
 
 // returns 0 when launched, 1 when the shape is not handled here, < 0 on error
@@ -541,7 +544,7 @@ int lcm_conv_halo_launch(HaloParams& hp, int B, hipStream_t s, int* slabs_per_im
     const int IH = ph ? p.Hin : hp.H, IW = ph ? p.Win : hp.W, PHM = ph ? 4 : 1;
     const int TW = halo_tw(IW);
     long long ws_bytes = 0;
-    p.ws = lcm_splitk_workspace(&ws_bytes);
+    p.ws = lcm_splitk_workspace(&ws_bytes, s);
     const int nchunks = p.Cin >> 6;
     const int m_img = p.M / B;
     p.img_rows = m_img;
@@ -571,13 +574,11 @@ int lcm_conv_halo_launch(HaloParams& hp, int B, hipStream_t s, int* slabs_per_im
     if (p.stats) {   // fused GroupNorm statistics of the output
         if (p.N > 2048) p.stats = nullptr;
         else if (splits > 1) {
-            p.reduce_rows = lcm_reduce_rows(hp.H * hp.W);
-            if (slabs_per_image) *slabs_per_image = hp.H * hp.W / p.reduce_rows;
+            if (slabs_per_image) *slabs_per_image = lcm_reduce_slabs(hp.H * hp.W);
         } else if (slabs_per_image) {
             *slabs_per_image = halo_slabs_per_image(IH, IW, TW, ph);      // canonical 32-pixel slabs (halo_slabs)
         }
     }
-    if (splits > 1 && p.reduce_rows <= 0) p.reduce_rows = lcm_reduce_rows(hp.H * hp.W);
     const bool xf = hp.gn_scale != nullptr;
     if (ph && xf) return 1;
 #define HALO_CASE(TH_, TW_, BN_)                                                           \

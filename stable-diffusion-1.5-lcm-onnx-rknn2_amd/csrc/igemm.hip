@@ -17,7 +17,7 @@
 // one shifted input pixel (zero-filled outside the image; optional fused nearest-2x upsample).
 #include "igemm_common.h"
 
-template <int BM, int BN, int MODE>
+template <int BM, int BN, int MODE, int LN = 0>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
     constexpr int RA = BM / 32, RW = BN / 32;   // staged rows per thread
     constexpr int TM = BM / 32, TN = BN / 32;   // 16-wide MFMA tiles per wave along m / n
@@ -113,6 +113,12 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
         for (int b = 0; b < TM; ++b) acc[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
 
     const int frow = lane & 15, fq = lane >> 4;
+    // LN is a compile-time switch: a run-time branch inside the K loop makes the compiler lose track of which LDS slot the
+    // LDS-DMA in flight writes, and it then drains the whole ring (s_waitcnt vmcnt(0)) before every fragment read
+    constexpr bool ln = LN != 0;
+    float ln_s[TM], ln_q[TM];
+#pragma unroll
+    for (int b = 0; b < TM; ++b) { ln_s[b] = 0.f; ln_q[b] = 0.f; }
 
     load_tile(kt0);
     store_tile(0);
@@ -137,6 +143,10 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
                 const int r = a * 16 + frow;
                 wf[a] = *reinterpret_cast<const h8*>(ws + r * 128 + ((c ^ (r & 7)) << 4));
             }
+            if constexpr (ln) {
+#pragma unroll
+                for (int b = 0; b < TM; ++b) ln_accum(xf[b], ln_s[b], ln_q[b]);
+            }
 #pragma unroll
             for (int a = 0; a < TN; ++a)
 #pragma unroll
@@ -159,7 +169,12 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmParams p) {
         const int r = m_base + wm * (BM / 2) + bp * 32;
         slab_of[bp] = r < p.M ? (r >> 5) : -1;
     }
-    igemm_epilogue<BM, BN>(p, acc, m_of, n_base + wn * (BN / 2), fq, z, slab_of);
+    if constexpr (ln) {
+        ln_finish<TM>(ln_s, ln_q, p.K, p.ln_eps);
+        igemm_epilogue<BM, BN>(p, acc, m_of, n_base + wn * (BN / 2), fq, z, slab_of, ln_s, ln_q);
+    } else {
+        igemm_epilogue<BM, BN>(p, acc, m_of, n_base + wn * (BN / 2), fq, z, slab_of);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -176,7 +191,7 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int MODE, int S>
+template <int BM, int BN, int MODE, int S, int LN = 0>
 __global__ __launch_bounds__(256, S == 1 ? (BM + BN < 256 ? 4 : 3) : 2) void igemm2_kernel(IgemmParams p) {
     constexpr int RA = BM / 32, RW = BN / 32;
     constexpr int TM = BM / 32, TN = BN / 32;
@@ -275,7 +290,21 @@ __global__ __launch_bounds__(256, S == 1 ? (BM + BN < 256 ? 4 : 3) : 2) void ige
         for (int b = 0; b < TM; ++b) acc[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
 
     const int frow = lane & 15, fq = lane >> 4;
+    // compile-time (see igemm_kernel).  The epilogue's ln_g / ln_c come from LDS, not from global memory: an ordinary
+    // VGPR-destination global load inside the K loop of a kernel that keeps LDS-DMA in flight makes the compiler drain the
+    // ring (s_waitcnt vmcnt(0)) in front of every fragment read (+50 % on the 64x64 launches, measured).
+    constexpr bool ln = LN != 0;
+    float ln_s[TM], ln_q[TM];
+#pragma unroll
+    for (int b = 0; b < TM; ++b) { ln_s[b] = 0.f; ln_q[b] = 0.f; }
 
+    const __attribute__((address_space(3))) float* ln_lds = nullptr;
+    if constexpr (ln) {       // this n-tile's ln_g | ln_c into LDS (behind the ring's stages) before any LDS-DMA is in flight
+        float* t = reinterpret_cast<float*>(smem + S * BUF);
+        if (tid < BN) { t[tid] = p.ln_g[nt0 * BN + tid]; t[BN + tid] = p.ln_c[nt0 * BN + tid]; }
+        __syncthreads();
+        ln_lds = (const __attribute__((address_space(3))) float*)t;
+    }
 #pragma unroll
     for (int s = 0; s < S - 1; ++s)
         if (s < T) issue_tile(s, s);
@@ -315,6 +344,10 @@ __global__ __launch_bounds__(256, S == 1 ? (BM + BN < 256 ? 4 : 3) : 2) void ige
                 const int r = a * 16 + frow;
                 wf[a] = *reinterpret_cast<const h8*>(ws + r * 128 + ((c ^ (r & 7)) << 4));
             }
+            if constexpr (ln) {            // the row statistics of A
+#pragma unroll
+                for (int b = 0; b < TM; ++b) ln_accum(xf[b], ln_s[b], ln_q[b]);
+            }
 #pragma unroll
             for (int a = 0; a < TN; ++a)
 #pragma unroll
@@ -336,7 +369,12 @@ __global__ __launch_bounds__(256, S == 1 ? (BM + BN < 256 ? 4 : 3) : 2) void ige
                 const int r = m_base + wm * (BM / 2) + bp * 32;
                 slab_of[bp] = r < p.M ? (r >> 5) : -1;
             }
-            igemm_epilogue<BM, BN>(p, acc, m_of, (nt0 + ni_cur) * BN + wn * (BN / 2), fq, z, slab_of);
+            if constexpr (ln) {
+                ln_finish<TM>(ln_s, ln_q, p.K, p.ln_eps);
+                igemm_epilogue<BM, BN>(p, acc, m_of, (nt0 + ni_cur) * BN + wn * (BN / 2), fq, z, slab_of, ln_s, ln_q, ln_lds, nt0 * BN);
+            } else {
+                igemm_epilogue<BM, BN>(p, acc, m_of, (nt0 + ni_cur) * BN + wn * (BN / 2), fq, z, slab_of);
+            }
             ++ni_cur;
 #pragma unroll
             for (int a = 0; a < TN; ++a)
@@ -353,7 +391,12 @@ __global__ __launch_bounds__(256, S == 1 ? (BM + BN < 256 ? 4 : 3) : 2) void ige
 __global__ __launch_bounds__(RED_THREADS) void splitk_reduce_kernel(IgemmParams p) {
     __shared__ float red[RED_THREADS * 4 * 2];
     const int n4 = p.N >> 2, tid = threadIdx.x;
-    const int r0 = blockIdx.x * p.reduce_rows, r1 = min(p.M, r0 + p.reduce_rows);
+    // workgroup = one slab of one image: rows [s * reduce_rows, (s+1) * reduce_rows) of image b, the last slab of an image
+    // may be short (image sizes that are no multiple of the slab height); slabs never straddle images
+    const int hw = p.img_rows > 0 ? p.img_rows : p.M;
+    const int spi = (hw + p.reduce_rows - 1) / p.reduce_rows;             // slabs per image
+    const int bimg = blockIdx.x / spi, sl = blockIdx.x - bimg * spi;
+    const int r0 = bimg * hw + sl * p.reduce_rows, r1 = min(bimg * hw + hw, r0 + p.reduce_rows);
     const long long slab = (long long)p.M * p.N;
     const bool small = n4 <= RED_THREADS;
     const int nrl = small ? RED_THREADS / n4 : 1;        // row lanes: threads that share a channel group
@@ -410,41 +453,58 @@ __global__ __launch_bounds__(RED_THREADS) void splitk_reduce_kernel(IgemmParams 
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+#include <map>
+#include <mutex>
 static float* g_ws[16] = {};
 static long long g_ws_bytes[16] = {};
+struct StreamWs { float* ptr; long long bytes; };
+static std::map<hipStream_t, StreamWs> g_stream_ws;       // lanes: one workspace per launch stream (two passes in flight
+static std::mutex g_ws_mu;                                // must not share slabs); falls back to the device-wide one
 
 extern "C" int lcm_set_workspace(void* ptr, int64_t bytes) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { lcm_set_error("set_workspace: no device"); return LCM_ENODEV; }
+    std::lock_guard<std::mutex> lk(g_ws_mu);
     g_ws[dev] = (float*)ptr;
     g_ws_bytes[dev] = ptr ? bytes : 0;
     return LCM_OK;
 }
-// rows per reduce workgroup: a power of two <= 32 that divides `hw` = output rows PER IMAGE (a slab never straddles two
-// images, and the slab structure -- hence the order in which the fused statistics are summed -- depends on the image
-// shape only, never on how many images share the launch) and leaves >= ~128 workgroups per image where it can
-int lcm_reduce_rows(int hw) {
-    int rs = 32;
-    while (rs > 1 && (hw / rs < 128 || hw % rs)) rs >>= 1;
-    return rs;
+
+extern "C" int lcm_set_stream_workspace(void* stream, void* ptr, int64_t bytes) {
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    if (ptr) g_stream_ws[(hipStream_t)stream] = StreamWs{(float*)ptr, (long long)bytes};
+    else g_stream_ws.erase((hipStream_t)stream);
+    return LCM_OK;
 }
 
-void lcm_launch_splitk_reduce(IgemmParams& p, hipStream_t s) {
-    if (p.reduce_rows <= 0) p.reduce_rows = lcm_reduce_rows(p.img_rows > 0 ? p.img_rows : p.M);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((p.M + p.reduce_rows - 1) / p.reduce_rows)), dim3(RED_THREADS), 0, s, p);
-}
-
-float* lcm_splitk_workspace(long long* bytes) {
+float* lcm_splitk_workspace(long long* bytes, hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    auto it = g_stream_ws.find(s);
+    if (it != g_stream_ws.end()) { *bytes = it->second.bytes; return it->second.ptr; }
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 16) { *bytes = 0; return nullptr; }
     *bytes = g_ws[dev] ? g_ws_bytes[dev] : 0;
     return g_ws[dev];
 }
+// rows per reduce workgroup: a power of two <= 32 chosen from `hw` = output rows PER IMAGE only (the slab structure --
+// hence the order in which the fused statistics are summed -- depends on the image shape, never on how many images share
+// the launch) so that an image has >= ~128 slabs where it can; ceil(hw / rows) slabs per image, the last one may be short
+int lcm_reduce_rows(int hw) {
+    int rs = 32;
+    while (rs > 1 && (hw + rs - 1) / rs < 128) rs >>= 1;
+    return rs;
+}
+int lcm_reduce_slabs(int hw) { const int rs = lcm_reduce_rows(hw); return (hw + rs - 1) / rs; }
+
+void lcm_launch_splitk_reduce(IgemmParams& p, hipStream_t s) {
+    const int hw = p.img_rows > 0 && p.M % p.img_rows == 0 ? p.img_rows : p.M;
+    p.img_rows = hw;
+    p.reduce_rows = lcm_reduce_rows(hw);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((p.M / hw) * lcm_reduce_slabs(hw))), dim3(RED_THREADS), 0, s, p);
+}
 
 // ---- per-shape launch plans (filled by the host-side autotuner; heuristics below are the fallback) ----
-#include <map>
-#include <mutex>
 #include <tuple>
 struct PlanVal { int bm, bn, splits, variant; };
 static std::map<std::tuple<int, int, int, int, int>, PlanVal> g_plans;
@@ -486,6 +546,7 @@ bool lcm_plan_get(int kind, int M, int N, int K, int aux, int* bm, int* bn, int*
 // entry of the TOTAL shape (tuned freely) or the occupancy heuristic.
 struct TilePick { int bm, bn, splits; };
 static int g_target_wgs = 384, g_max_splits = 16, g_min_wgs = 256;
+static int g_split_max_rows = 1024, g_split_cap = 4;
 static int g_variant = -1;     // -1: auto (1 stage when >= 4 workgroups per CU are available, else 2); 0: register-staged
                                // double buffer (v1); 1/2/3/4: LDS-DMA pipeline with that many stages
 
@@ -511,6 +572,13 @@ extern "C" int lcm_set_tuning(int target_wgs, int max_splits, int min_wgs) {
     if (target_wgs > 0) g_target_wgs = target_wgs;
     if (max_splits > 0) g_max_splits = max_splits;
     if (min_wgs > 0) g_min_wgs = min_wgs;
+    return LCM_OK;
+}
+
+extern "C" int lcm_set_split_policy(int max_rows_per_image, int max_parts) {
+    if (max_rows_per_image < 0 || max_parts < 1 || max_parts > 64) { lcm_set_error("split_policy: %d rows / %d parts", max_rows_per_image, max_parts); return LCM_EINVAL; }
+    g_split_max_rows = max_rows_per_image;
+    g_split_cap = max_parts;
     return LCM_OK;
 }
 
@@ -541,13 +609,23 @@ static TilePick pick_tile(int M, int N, int K, int batch, int fixed_splits) {
     return best;
 }
 
+// The partition is paid for at every batch size (a batch of 8 splits every image the way a lone image is split, and the
+// fp32 slabs then cost HBM traffic the batched launch would not otherwise need), so it is kept to where a lone image
+// cannot fill the chip any other way: at most 1024 output rows per image (the 32x32 latent level and below) and at most
+// 4 parts (at batch 1 the measured difference between 4 and 10 parts is within noise: profiles/r01_chain_latency_conv.txt).
+int lcm_split_policy(int m_img, int sp) {
+    if (m_img > g_split_max_rows) return 1;
+    if (sp > g_split_cap) sp = g_split_cap;
+    return sp < 1 ? 1 : sp;
+}
+
 // canonical split factor of a GEMM-kind contraction (kind 0: linear / 1x1, kind 1: row-gather 3x3) with `m_img`
 // output rows per image
 static int canonical_splits_gemm(int kind, int m_img, int N, int K) {
     int pbm, pbn, psp, pv;
     int sp = lcm_plan_get(kind, m_img, N, K, 1, &pbm, &pbn, &psp, &pv) ? psp : pick_tile(m_img, N, K, 1, -1).splits;
     if (sp > (K >> 6)) sp = K >> 6;
-    return sp < 1 ? 1 : sp;
+    return lcm_split_policy(m_img, sp);
 }
 
 int lcm_canonical_splits_halo(int m_img, int N, int K, int IH, int IW, int W, int ph, int xform);
@@ -568,19 +646,19 @@ extern "C" int lcm_gemm_tile_config(int M, int N, int batch) {
     return t.bm * 1000 + t.bn;
 }
 
-template <int BM, int BN, int MODE, int S>
+template <int BM, int BN, int MODE, int S, int LN = 0>
 static int launch_v2(IgemmParams& p, dim3 grid, hipStream_t s) {
-    constexpr int smem = S * (BM + BN) * 128;
+    constexpr int smem = S * (BM + BN) * 128 + (LN ? 2 * BN * 4 : 0);       // LN: + this n-tile's ln_g | ln_c
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<BM, BN, MODE, S>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<BM, BN, MODE, S, LN>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_set = true;
     }
     char nm[64];
-    snprintf(nm, sizeof(nm), "igemm2_kernel<%d, %d, %d, %d>%s", BM, BN, MODE, S, p.splits > 1 ? " +splitk" : "");
+    snprintf(nm, sizeof(nm), "igemm2_kernel<%d, %d, %d, %d, %d>%s", BM, BN, MODE, S, LN, p.splits > 1 ? " +splitk" : "");
     lcm_prof_start(nm, s);
-    hipLaunchKernelGGL((igemm2_kernel<BM, BN, MODE, S>), grid, dim3(256), smem, s, p);
+    hipLaunchKernelGGL((igemm2_kernel<BM, BN, MODE, S, LN>), grid, dim3(256), smem, s, p);
     lcm_prof_stop(s);
     return 0;
 }
@@ -591,7 +669,7 @@ static int g_persist_n = 0;      // 1: short-K GEMM launches let a workgroup wal
 
 extern "C" int lcm_set_persist_n(int on) { g_persist_n = on ? 1 : 0; return LCM_OK; }
 
-template <int BM, int BN, int MODE>
+template <int BM, int BN, int MODE, int LN = 0>
 static int launch_cfg(IgemmParams& p, int batch, int splits, int plan_variant, hipStream_t s) {
     p.mtiles = (p.M + BM - 1) / BM;
     p.ntiles = p.N / BN;
@@ -599,7 +677,7 @@ static int launch_cfg(IgemmParams& p, int batch, int splits, int plan_variant, h
     p.n_iters = 1;
     int variant = g_variant >= 0 ? g_variant : plan_variant;
     // persistent-over-N: short K (<= 20 k-tiles), several n-tiles, and more tiles than the chip can hold at once
-    if (g_persist_n && MODE == 0 && splits == 1 && batch == 1 && variant != 0 && p.ntiles > 1 && (p.K >> 6) <= 20 &&
+    if (g_persist_n && MODE == 0 && !LN && splits == 1 && batch == 1 && variant != 0 && p.ntiles > 1 && (p.K >> 6) <= 20 &&
         (long long)p.mtiles * p.ntiles > 512) {
         int ni = p.ntiles;                                         // largest divisor of ntiles keeping >= 384 workgroups
         while (ni > 1 && (p.ntiles % ni != 0 || (long long)p.mtiles * (p.ntiles / ni) < 384)) --ni;
@@ -619,25 +697,25 @@ static int launch_cfg(IgemmParams& p, int batch, int splits, int plan_variant, h
         const int smem = 2 * (BM + BN) * 128;
         static bool attr_set = false;
         if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, MODE>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, MODE, LN>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem);
             attr_set = true;
         }
         char nm[64];
-        snprintf(nm, sizeof(nm), "igemm_kernel<%d, %d, %d>%s", BM, BN, MODE, p.splits > 1 ? " +splitk" : "");
+        snprintf(nm, sizeof(nm), "igemm_kernel<%d, %d, %d, %d>%s", BM, BN, MODE, LN, p.splits > 1 ? " +splitk" : "");
         lcm_prof_start(nm, s);
-        hipLaunchKernelGGL((igemm_kernel<BM, BN, MODE>), grid, dim3(256), smem, s, p);
+        hipLaunchKernelGGL((igemm_kernel<BM, BN, MODE, LN>), grid, dim3(256), smem, s, p);
         lcm_prof_stop(s);
     } else if (variant == 1) {
-        launch_v2<BM, BN, MODE, 1>(p, grid, s);
+        launch_v2<BM, BN, MODE, 1, LN>(p, grid, s);
     } else if (variant == 2) {
-        launch_v2<BM, BN, MODE, 2>(p, grid, s);
+        launch_v2<BM, BN, MODE, 2, LN>(p, grid, s);
     } else if (variant == 3) {
-        launch_v2<BM, BN, MODE, 3>(p, grid, s);
+        launch_v2<BM, BN, MODE, 3, LN>(p, grid, s);
     } else if (variant == 6) {
-        if constexpr (BM + BN <= 128) launch_v2<BM, BN, MODE, 6>(p, grid, s);
+        if constexpr (BM + BN <= 128) launch_v2<BM, BN, MODE, 6, LN>(p, grid, s);
     } else {
-        launch_v2<BM, BN, MODE, 4>(p, grid, s);
+        launch_v2<BM, BN, MODE, 4, LN>(p, grid, s);
     }
     LCM_CHECK_LAUNCH("igemm");
     if (splits > 1) {
@@ -653,10 +731,8 @@ static int launch_cfg(IgemmParams& p, int batch, int splits, int plan_variant, h
 template <int MODE>
 static int launch_igemm(IgemmParams& p, int batch, hipStream_t s, int img_rows, bool allow_split, bool want_stats,
                         int* slabs_per_image) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    p.ws = (dev >= 0 && dev < 16) ? g_ws[dev] : nullptr;
-    const long long wsb = p.ws ? g_ws_bytes[dev] : 0;
+    long long wsb = 0;
+    p.ws = lcm_splitk_workspace(&wsb, s);
     if (img_rows <= 0 || p.M % img_rows) img_rows = p.M;
     p.img_rows = img_rows;
     int splits = 1;
@@ -682,16 +758,24 @@ static int launch_igemm(IgemmParams& p, int batch, hipStream_t s, int img_rows, 
     p.stats = want_stats ? p.stats : nullptr;
     if (p.stats) {
         const bool ok = p.epi == 0 && batch == 1 && p.N <= 2048 && img_rows % 32 == 0;
-        if (ok && splits > 1) {
-            p.reduce_rows = lcm_reduce_rows(img_rows);
-            if (slabs_per_image) *slabs_per_image = img_rows / p.reduce_rows;
+        if (p.epi == 0 && batch == 1 && p.N <= 2048 && splits > 1) {      // reduce slabs: any image size
+            if (slabs_per_image) *slabs_per_image = lcm_reduce_slabs(img_rows);
         } else if (ok) {
             if (slabs_per_image) *slabs_per_image = img_rows / 32;       // canonical 32-row slabs (igemm_epilogue)
         }
-        if (!ok) p.stats = nullptr;
+        if (!ok && !(p.epi == 0 && batch == 1 && p.N <= 2048 && splits > 1)) p.stats = nullptr;
     }
-    if (splits > 1 && p.reduce_rows <= 0) p.reduce_rows = lcm_reduce_rows(img_rows);
     const int code = t.bm * 1000 + t.bn;
+    if constexpr (MODE == 0) if (p.ln_g) {     // LayerNorm-folded GEMM: its own instantiations (compile-time switch in the K loop)
+        switch (code) {
+            case 128128: return launch_cfg<128, 128, 0, 1>(p, batch, splits, variant, s);
+            case 128064: return launch_cfg<128, 64, 0, 1>(p, batch, splits, variant, s);
+            case 64128: return launch_cfg<64, 128, 0, 1>(p, batch, splits, variant, s);
+            case 128160: return launch_cfg<128, 160, 0, 1>(p, batch, splits, variant, s);
+            case 64160: return launch_cfg<64, 160, 0, 1>(p, batch, splits, variant, s);
+            default: return launch_cfg<64, 64, 0, 1>(p, batch, splits, variant, s);
+        }
+    }
     switch (code) {
         case 128128: return launch_cfg<128, 128, MODE>(p, batch, splits, variant, s);
         case 128064: return launch_cfg<128, 64, MODE>(p, batch, splits, variant, s);
@@ -732,6 +816,26 @@ extern "C" int lcm_gemm_f16(const void* A, int lda, const void* A2, int lda2, in
     return launch_igemm<0>(p, batch, (hipStream_t)stream, img_rows, allow_split, stats_out != nullptr, slabs_per_image);
 }
 
+// LayerNorm -> Linear as ONE contraction (BasicTransformerBlock norm1->attn1.to_q|k|v, norm2->attn2.to_q, norm3->ff.net.0):
+//   LN(x) W^T + b = rstd * (x (gamma (*) W)^T - mean * g) + c,   g[n] = sum_k (gamma (*) W)[n][k],  c[n] = sum_k beta[k] W[n][k] + b[n]
+// W must hold gamma (*) W (fp16), ln_g / ln_c fp32 [N].  The row statistics are accumulated from the A fragments while the
+// kernel walks K (each wave sees every k of its rows), so the LayerNorm costs no launch and no pass over HBM.  Never split
+// over K.  Epilogues: LCM_EPI_NONE or LCM_EPI_GEGLU (ln_g / ln_c in the packed row order of W).
+extern "C" int lcm_gemm_ln_f16(const void* A, int lda, const void* W, const void* ln_g, const void* ln_c, float eps,
+                               void* out, int ldo, int M, int N, int K, int epilogue, int img_rows, void* stream) {
+    LCM_REQUIRE(A && W && out && ln_g && ln_c, "gemm_ln: null pointer");
+    LCM_REQUIRE(M > 0 && N > 0 && K > 0, "gemm_ln: bad shape M=%d N=%d K=%d", M, N, K);
+    LCM_REQUIRE(K % 64 == 0 && N % 64 == 0, "gemm_ln: N=%d K=%d must be multiples of 64", N, K);
+    LCM_REQUIRE(lda % 8 == 0 && ldo % 4 == 0, "gemm_ln: lda=%d (%%8) / ldo=%d (%%4) misaligned", lda, ldo);
+    LCM_REQUIRE(epilogue == 0 || epilogue == 1, "gemm_ln: epilogue %d (0 = none, 1 = GEGLU)", epilogue);
+    IgemmParams p = {};
+    p.A = (const half_t*)A; p.W = (const half_t*)W; p.out = (half_t*)out;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.K1 = K; p.ldo = ldo; p.rows_per_batch = 1;
+    p.epi = epilogue; p.out_scale = 1.0f;
+    p.ln_g = (const float*)ln_g; p.ln_c = (const float*)ln_c; p.ln_eps = eps;
+    return launch_igemm<0>(p, 1, (hipStream_t)stream, img_rows, false, false, nullptr);
+}
+
 struct HaloParams {
     IgemmParams g;
     int C1;
@@ -763,7 +867,9 @@ extern "C" int lcm_conv3x3_gn_f16(const void* in, int C1, const void* in2, int C
     const int crop_h = (ups >> 2) & 1, crop_w = (ups >> 3) & 1;
     ups &= 3;
     LCM_REQUIRE(ups >= 0 && ups <= 2 && !(ups == 2 && gn_scale), "conv3x3_gn: ups=%d (2 = phase-packed weights, no fused GroupNorm)", ups);
-    LCM_REQUIRE(ups != 0 || (!crop_h && !crop_w), "conv3x3_gn: output crop flags need an upsampling mode");
+    // (the conv sees ZERO padding beyond the cropped upsampled image, so the border outputs use fewer taps than the
+    // pre-summed phase weights of ups=2 hold: odd targets take the loader-fused form, ups=1, with the plain 3x3 weights)
+    LCM_REQUIRE(ups == 1 || (!crop_h && !crop_w), "conv3x3_gn: an odd output size needs ups=1 (plain 3x3 weights), got ups=%d", ups);
     p.Hin = Hin; p.Win = Win; p.Cin = Cin; p.stride = 1; p.ups = ups;
     hp.H = ups ? 2 * Hin - crop_h : Hin; hp.W = ups ? 2 * Win - crop_w : Win;
     p.Hout = hp.H; p.Wout = hp.W;

@@ -26,6 +26,11 @@ struct IgemmParams {
                          // squares) of the fp16-rounded values each half-tile (or reduce slab) stores; null = off
     int reduce_rows;     // rows per workgroup of splitk_reduce_kernel
     int img_rows;        // output rows per image (GEMM kinds; 0 = one image)
+    // LayerNorm folded into the GEMM that consumes it (lcm_gemm_ln_f16): W holds gamma (*) W, the kernel accumulates the
+    // row sums of A while it walks K and the epilogue applies  y = rstd * (acc - mean * ln_g[n]) + ln_c[n]
+    const float* ln_g;   // [N] fp32: sum_k W'[n][k]   (null = plain GEMM)
+    const float* ln_c;   // [N] fp32: sum_k beta[k] W[n][k] + bias[n]
+    float ln_eps;
     int n_iters;         // igemm2: consecutive n-tiles one workgroup walks with a continuous LDS-DMA pipeline (>= 1)
 };
 
@@ -35,9 +40,41 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
 }
 
+// LayerNorm fold: per-lane partial row sums of an A fragment (8 fp16 of row m = b*16 + frow): v_dot2_f32_f16 with (1,1)
+// and with itself.  The 4 lanes (fq = 0..3) that share a row cover the 64 channels of a k-tile between them.
+__device__ __forceinline__ void ln_accum(const h8& x, float& s, float& q) {
+    const h2 one = {(half_t)1.0f, (half_t)1.0f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const h2 pr = {x[2 * i], x[2 * i + 1]};
+        s = __builtin_amdgcn_fdot2(pr, one, s, false);
+        q = __builtin_amdgcn_fdot2(pr, pr, q, false);
+    }
+}
+// fold the 4 fq-lanes of a row (fixed butterfly order) and turn (sum, sum of squares) into (mean, rstd)
+template <int TM>
+__device__ __forceinline__ void ln_finish(float (&s)[TM], float (&q)[TM], int K, float eps) {
+    const float inv = 1.0f / (float)K;
+#pragma unroll
+    for (int b = 0; b < TM; ++b) {
+        float ss = s[b], qq = q[b];
+        ss += __shfl_xor(ss, 16, 64); qq += __shfl_xor(qq, 16, 64);
+        ss += __shfl_xor(ss, 32, 64); qq += __shfl_xor(qq, 32, 64);
+        const float mean = ss * inv;
+        s[b] = mean;
+        q[b] = rsqrtf(fmaxf(qq * inv - mean * mean, 0.f) + eps);
+    }
+}
+
 template <int BM, int BN>
 __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f4 (&acc)[BN / 32][BM / 32], const int (&m_of)[BM / 32],
-                                               int n_wave, int fq, int z, const int (&slab_of)[BM / 64]) {
+                                               int n_wave, int fq, int z, const int (&slab_of)[BM / 64],
+                                               const float* ln_mu = nullptr, const float* ln_r = nullptr,
+                                               const __attribute__((address_space(3))) float* ln_lds = nullptr, int n_tile0 = 0) {
+    // ln_lds: the BN entries of ln_g then of ln_c of this n-tile (first channel n_tile0), staged in LDS by the kernel --
+    // an ordinary global load here, inside the K loop of a kernel that keeps LDS-DMA in flight, makes the compiler drain
+    // the DMA ring (s_waitcnt vmcnt(0)) in front of every fragment read
+    // ln_mu / ln_r: per fragment b, mean and rstd of this lane's row (LayerNorm fold), or null
     // m_of[b]: global output row of this lane in m-tile b, or -1 (outside the problem); n_wave: first channel of
     // this wave's BN/2-wide slice.  slab_of[bp]: index of the CANONICAL statistics slab that the fragment pair
     // (2bp, 2bp+1) of this wave covers (32 output pixels: 32 consecutive rows of a GEMM, a 2x16 / 4x8 pixel patch of a
@@ -72,6 +109,12 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f4 (&acc)[B
             const int n = n_wave + a * 16 + fq * 4;
             f4 bias4 = {0.f, 0.f, 0.f, 0.f};
             if (p.bias) { h4 t = *reinterpret_cast<const h4*>(p.bias + n); bias4 = (f4){(float)t[0], (float)t[1], (float)t[2], (float)t[3]}; }
+            f4 lng4 = {0.f, 0.f, 0.f, 0.f}, lnc4 = {0.f, 0.f, 0.f, 0.f};
+            if (ln_mu) {
+                if (ln_lds) { lng4 = *reinterpret_cast<const __attribute__((address_space(3))) f4*>(ln_lds + (n - n_tile0));
+                              lnc4 = *reinterpret_cast<const __attribute__((address_space(3))) f4*>(ln_lds + BN + (n - n_tile0)); }
+                else { lng4 = *reinterpret_cast<const f4*>(p.ln_g + n); lnc4 = *reinterpret_cast<const f4*>(p.ln_c + n); }
+            }
 #pragma unroll
             for (int bp = 0; bp < TM / 2; ++bp) {
                 float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
@@ -80,6 +123,10 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f4 (&acc)[B
                     const int m = m_of[b];
                     if (m < 0) continue;
                     f4 v = acc[a][b];
+                    if (ln_mu) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = ln_r[b] * (v[j] - ln_mu[b] * lng4[j]) + lnc4[j];
+                    }
                     v[0] += bias4[0]; v[1] += bias4[1]; v[2] += bias4[2]; v[3] += bias4[3];
                     if (p.rowadd) { h4 t = *reinterpret_cast<const h4*>(p.rowadd + (long long)(m / p.rows_per_batch) * p.ld_rowadd + n);
                         v[0] += (float)t[0]; v[1] += (float)t[1]; v[2] += (float)t[2]; v[3] += (float)t[3]; }
@@ -129,11 +176,31 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f4 (&acc)[B
                 bg = (f4){(float)tg[0], (float)tg[1], (float)tg[2], (float)tg[3]};
             }
             const int nout = ((n_wave + a * 16) >> 1) + fq * 4;
+            f4 gx = {0.f, 0.f, 0.f, 0.f}, cx = gx, gg = gx, cg = gx;
+            if (ln_mu) {
+                if (ln_lds) {
+                    const __attribute__((address_space(3))) float* gl = ln_lds + (n - n_tile0);
+                    gx = *reinterpret_cast<const __attribute__((address_space(3))) f4*>(gl);
+                    cx = *reinterpret_cast<const __attribute__((address_space(3))) f4*>(gl + BN);
+                    gg = *reinterpret_cast<const __attribute__((address_space(3))) f4*>(gl + 16);
+                    cg = *reinterpret_cast<const __attribute__((address_space(3))) f4*>(gl + BN + 16);
+                } else {
+                    gx = *reinterpret_cast<const f4*>(p.ln_g + n); cx = *reinterpret_cast<const f4*>(p.ln_c + n);
+                    gg = *reinterpret_cast<const f4*>(p.ln_g + n + 16); cg = *reinterpret_cast<const f4*>(p.ln_c + n + 16);
+                }
+            }
 #pragma unroll
             for (int b = 0; b < TM; ++b) {
                 const int m = m_of[b];
                 if (m < 0) continue;
                 f4 x = acc[a][b], g = acc[a + 1][b];
+                if (ln_mu) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        x[j] = ln_r[b] * (x[j] - ln_mu[b] * gx[j]) + cx[j];
+                        g[j] = ln_r[b] * (g[j] - ln_mu[b] * gg[j]) + cg[j];
+                    }
+                }
                 h4 o;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o[j] = (half_t)((x[j] + bx[j]) * gelu_erf_f(g[j] + bg[j]));

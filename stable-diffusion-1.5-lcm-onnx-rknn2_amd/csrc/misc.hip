@@ -399,6 +399,40 @@ extern "C" int lcm_axpy_f16(const void* base, const void* delta, float alpha, vo
 }
 
 // ---------------------------------------------------------------------------------------------
+// Constants of a LayerNorm folded into its consumer GEMM (lcm_gemm_ln_f16), refreshed after the live weight W' changed
+// (style LoRA re-merge): g[n] = sum_k W'[n][k] from the fp16 values the kernel will multiply with, c[n] = c_base[n] +
+// alpha * c_delta[n].  One wave per output feature.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ln_fold_refresh_kernel(const half_t* __restrict__ W, int N, int K,
+                                                              const float* __restrict__ c_base, const float* __restrict__ c_delta,
+                                                              float alpha, float* __restrict__ g_out, float* __restrict__ c_out) {
+    const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const half_t* wr = W + (long long)n * K;
+    float s = 0.f;
+    for (int k = lane * 8; k < K; k += 512) {
+        h8 w = *reinterpret_cast<const h8*>(wr + k);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += (float)w[j];
+    }
+    s = wave_sum(s);
+    if (lane == 0) {
+        g_out[n] = s;
+        if (c_out) c_out[n] = c_base[n] + (c_delta ? alpha * c_delta[n] : 0.f);
+    }
+}
+
+extern "C" int lcm_ln_fold_refresh(const void* W, int N, int K, const void* c_base, const void* c_delta, float alpha,
+                                   void* g_out, void* c_out, void* stream) {
+    LCM_REQUIRE(W && g_out && N > 0 && K > 0 && K % 8 == 0, "ln_fold_refresh: bad args");
+    LCM_REQUIRE(!c_out || c_base, "ln_fold_refresh: c_out needs c_base");
+    hipLaunchKernelGGL(ln_fold_refresh_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const half_t*)W, N, K,
+                       (const float*)c_base, (const float*)c_delta, alpha, (float*)g_out, (float*)c_out);
+    LCM_CHECK_LAUNCH("ln_fold_refresh");
+    return LCM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // AutoencoderKL.tiled_decode glue (vae.enable_tiling(), backends/cuda_worker.py:91): linear blends of
 // overlapping decoded tiles (float pixel-major [B,h,w,3]) and the crop + place + RGB8 conversion of the result.
 // ---------------------------------------------------------------------------------------------

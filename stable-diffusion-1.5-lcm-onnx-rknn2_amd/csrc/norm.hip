@@ -164,20 +164,15 @@ __global__ __launch_bounds__(64) void gn_finalize_affine_kernel(const float* __r
     }
 }
 
-// GroupNorm affine from the per-channel partial statistics the producing contraction kernel wrote in its epilogue
-// (csrc/igemm_common.h): stats[(b*P + p)][C][2].  One workgroup per (image, group); the group's channels may span
-// both sources of a fused concat.  Fixed-order reduction (thread-sequential, then an LDS tree): deterministic.
-__global__ __launch_bounds__(256) void gn_finalize_from_stats_kernel(const float* __restrict__ st1, int P1, int C1,
-                                                                     const float* __restrict__ st2, int P2, int C2,
-                                                                     const half_t* __restrict__ gamma, const half_t* __restrict__ beta,
-                                                                     float* __restrict__ scale, float* __restrict__ shift,
-                                                                     int groups, float inv_count, float eps) {
-    __shared__ float rs[256], rq[256];
-    const int C = C1 + C2, cpg = C / groups;
-    const int bg = blockIdx.x, b = bg / groups, g = bg - b * groups, tid = threadIdx.x;
-    const int c_lo = g * cpg, c_hi = c_lo + cpg;
+// GroupNorm statistics of one (image, group) from the per-channel partial statistics the producing contraction kernel
+// wrote in its epilogue (csrc/igemm_common.h): stats[(b*P + p)][C][2].  The group's channels may span both sources of a
+// fused concat.  ONE routine for the finalize kernel and the single-launch kernel below (which of the two runs depends on
+// the tensor size, hence on the batch: they must agree bit for bit).  Fixed order: thread-sequential over slabs (4 in
+// flight), wave butterfly, then the 4 wave sums in wave order.  `red` = 8 floats of LDS.  Returns (mean, rstd) to every thread.
+__device__ __forceinline__ float2 gn_group_stats(const float* __restrict__ st1, int P1, int C1, const float* __restrict__ st2, int P2,
+                                                 int C2, int b, int c_lo, int c_hi, float inv_count, float eps, float* red) {
+    const int tid = threadIdx.x;
     float s = 0.f, q = 0.f;
-    // thread -> (slab lane, channel of the group); slabs are walked 4 at a time with independent loads
     auto accumulate = [&](const float* __restrict__ st, int P, int Cs, int a, int w) {
         if (w <= 0 || st == nullptr) return;
         const int spl = 256 / w;                   // slab lanes
@@ -201,90 +196,90 @@ __global__ __launch_bounds__(256) void gn_finalize_from_stats_kernel(const float
     };
     accumulate(st1, P1, C1, c_lo, min(c_hi, C1) - c_lo);                       // channels of the group in source 1
     accumulate(st2, P2, C2, max(c_lo, C1) - C1, c_hi - max(c_lo, C1));         // ... and in source 2
-    rs[tid] = s; rq[tid] = q;
+    s = wave_sum(s); q = wave_sum(q);
+    if ((tid & 63) == 0) { red[(tid >> 6) * 2] = s; red[(tid >> 6) * 2 + 1] = q; }
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (tid < o) { rs[tid] += rs[tid + o]; rq[tid] += rq[tid + o]; }
-        __syncthreads();
-    }
-    const float mean = rs[0] * inv_count;
-    const float rstd = rsqrtf(fmaxf(rq[0] * inv_count - mean * mean, 0.f) + eps);
+    const float ts = ((red[0] + red[2]) + red[4]) + red[6];
+    const float tq = ((red[1] + red[3]) + red[5]) + red[7];
+    const float mean = ts * inv_count;
+    return make_float2(mean, rsqrtf(fmaxf(tq * inv_count - mean * mean, 0.f) + eps));
+}
+
+__global__ __launch_bounds__(256) void gn_finalize_from_stats_kernel(const float* __restrict__ st1, int P1, int C1,
+                                                                     const float* __restrict__ st2, int P2, int C2,
+                                                                     const half_t* __restrict__ gamma, const half_t* __restrict__ beta,
+                                                                     float* __restrict__ scale, float* __restrict__ shift,
+                                                                     int groups, float inv_count, float eps) {
+    __shared__ float red[8];
+    const int C = C1 + C2, cpg = C / groups;
+    const int bg = blockIdx.x, b = bg / groups, g = bg - b * groups, tid = threadIdx.x;
+    const int c_lo = g * cpg;
+    const float2 mr = gn_group_stats(st1, P1, C1, st2, P2, C2, b, c_lo, c_lo + cpg, inv_count, eps, red);
     for (int j = tid; j < cpg; j += 256) {
         const int c = c_lo + j;
-        const float a = rstd * (float)gamma[c];
+        const float a = mr.y * (float)gamma[c];
         scale[(long long)b * C + c] = a;
-        shift[(long long)b * C + c] = (float)beta[c] - mean * a;
+        shift[(long long)b * C + c] = (float)beta[c] - mr.x * a;
     }
 }
 
 // One launch for SMALL tensors (batch 1-2 UNet levels, the VAE's 64^2 level), where finalize + apply are two launches
 // at the ~3 us launch floor each: workgroup (pixel slice, image, group) re-derives its group's mean / rstd from the
 // producer statistics -- P * cpg * 8 bytes out of L2, cheap to repeat per slice -- and applies the affine (+SiLU) to its
-// slice of pixels for the group's cpg channels.  Same arithmetic as the two-launch path.
+// slice of pixels for the group's cpg channels.  Same arithmetic as the two-launch path.  The first GN_PRE activation
+// pairs of every thread are fetched BEFORE the statistics are reduced: the two dependent memory round trips of the kernel
+// (statistics, then activations) overlap instead of adding up (the kernel is pure latency at these sizes).
 typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+#define GN_PRE 6
 __global__ __launch_bounds__(256) void gn_from_stats_fused_kernel(const half_t* __restrict__ x, int C1, const half_t* __restrict__ x2, int C2,
                                                                   const float* __restrict__ st1, int P1, const float* __restrict__ st2, int P2,
                                                                   const half_t* __restrict__ gamma, const half_t* __restrict__ beta,
                                                                   half_t* __restrict__ out, int HW, int groups, float inv_count, float eps,
                                                                   int silu, int rows_per_wg) {
-    __shared__ float rs[256], rq[256];
+    __shared__ float red[8];
     __shared__ float sc_s[128], sh_s[128];
     const int C = C1 + C2, cpg = C / groups;
     const int bg = blockIdx.y, b = bg / groups, g = bg - b * groups, tid = threadIdx.x;
-    const int c_lo = g * cpg, c_hi = c_lo + cpg;
-    float s = 0.f, q = 0.f;
-    auto accumulate = [&](const float* __restrict__ st, int P, int Cs, int a, int w) {
-        if (w <= 0 || st == nullptr) return;
-        const int spl = 256 / w;
-        const int sl = tid / w, jc = tid - sl * w;
-        if (sl >= spl) return;
-        const float* base = st + ((long long)b * P * Cs + a + jc) * 2;
-        const long long stride = (long long)Cs * 2;
-        int pp = sl;
-        for (; pp + 3 * spl < P; pp += 4 * spl) {
-            const float2 v0 = *reinterpret_cast<const float2*>(base + pp * stride);
-            const float2 v1 = *reinterpret_cast<const float2*>(base + (pp + spl) * stride);
-            const float2 v2 = *reinterpret_cast<const float2*>(base + (pp + 2 * spl) * stride);
-            const float2 v3 = *reinterpret_cast<const float2*>(base + (pp + 3 * spl) * stride);
-            s += (v0.x + v1.x) + (v2.x + v3.x);
-            q += (v0.y + v1.y) + (v2.y + v3.y);
-        }
-        for (; pp < P; pp += spl) {
-            const float2 v = *reinterpret_cast<const float2*>(base + pp * stride);
-            s += v.x; q += v.y;
-        }
-    };
-    accumulate(st1, P1, C1, c_lo, min(c_hi, C1) - c_lo);
-    accumulate(st2, P2, C2, max(c_lo, C1) - C1, c_hi - max(c_lo, C1));
-    rs[tid] = s; rq[tid] = q;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (tid < o) { rs[tid] += rs[tid + o]; rq[tid] += rq[tid + o]; }
-        __syncthreads();
-    }
-    const float mean = rs[0] * inv_count;
-    const float rstd = rsqrtf(fmaxf(rq[0] * inv_count - mean * mean, 0.f) + eps);
-    if (tid < cpg) {
-        const float a = rstd * (float)gamma[c_lo + tid];
-        sc_s[tid] = a;
-        sh_s[tid] = (float)beta[c_lo + tid] - mean * a;
-    }
-    __syncthreads();
+    const int c_lo = g * cpg;
     // apply: work item = (pixel, channel pair of the group); consecutive threads take consecutive pairs of one pixel
     const int hp = cpg >> 1;
     const int r0 = blockIdx.x * rows_per_wg, r1 = min(HW, r0 + rows_per_wg);
     const long long rowbase = (long long)b * HW;
     const int items = (r1 - r0) * hp;
-    for (int i = tid; i < items; i += 256) {
+    auto load_item = [&](int i) -> h2v {
         const int pr = i / hp, j = i - pr * hp;
         const int c = c_lo + 2 * j;
         const long long row = rowbase + r0 + pr;
-        const h2v v = (c < C1) ? *reinterpret_cast<const h2v*>(x + row * C1 + c) : *reinterpret_cast<const h2v*>(x2 + row * C2 + (c - C1));
+        return (c < C1) ? *reinterpret_cast<const h2v*>(x + row * C1 + c) : *reinterpret_cast<const h2v*>(x2 + row * C2 + (c - C1));
+    };
+    h2v pre[GN_PRE];
+#pragma unroll
+    for (int k = 0; k < GN_PRE; ++k) {
+        const int i = tid + 256 * k;
+        pre[k] = (i < items) ? load_item(i) : (h2v){(half_t)0, (half_t)0};
+    }
+    const float2 mr = gn_group_stats(st1, P1, C1, st2, P2, C2, b, c_lo, c_lo + cpg, inv_count, eps, red);
+    if (tid < cpg) {
+        const float a = mr.y * (float)gamma[c_lo + tid];
+        sc_s[tid] = a;
+        sh_s[tid] = (float)beta[c_lo + tid] - mr.x * a;
+    }
+    __syncthreads();
+    auto apply_store = [&](int i, h2v v) {
+        const int pr = i / hp, j = i - pr * hp;
+        const int c = c_lo + 2 * j;
+        const long long row = rowbase + r0 + pr;
         float f0 = (float)v[0] * sc_s[2 * j] + sh_s[2 * j], f1 = (float)v[1] * sc_s[2 * j + 1] + sh_s[2 * j + 1];
         if (silu) { f0 = silu_f(f0); f1 = silu_f(f1); }
         h2v o = {(half_t)f0, (half_t)f1};
         *reinterpret_cast<h2v*>(out + row * C + c) = o;
+    };
+#pragma unroll
+    for (int k = 0; k < GN_PRE; ++k) {
+        const int i = tid + 256 * k;
+        if (i < items) apply_store(i, pre[k]);
     }
+    for (int i = tid + 256 * GN_PRE; i < items; i += 256) apply_store(i, load_item(i));
 }
 
 static long long g_gn_fused_bytes = 8ll << 20;   // tensors up to this size take the single-launch path above

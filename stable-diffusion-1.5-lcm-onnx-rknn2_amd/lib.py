@@ -33,6 +33,8 @@ _vp, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
 _SIGS = {
     "lcm_gemm_f16": [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _i,
                      _i64, _i64, _i64, _i, _vp, C.POINTER(_i), _vp],
+    "lcm_gemm_ln_f16": [_vp, _i, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "lcm_ln_fold_refresh": [_vp, _i, _i, _vp, _vp, _f, _vp, _vp, _vp],
     "lcm_conv3x3_f16": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, C.POINTER(_i), _vp],
     "lcm_groupnorm_from_stats_f16": [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp],
     "lcm_conv3x3_c4_f32in": [_vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
@@ -59,7 +61,9 @@ _SIGS = {
     "lcm_profile_begin": [_i],
     "lcm_profile_end": [C.c_char_p, _i64],
     "lcm_set_workspace": [_vp, _i64],
+    "lcm_set_stream_workspace": [_vp, _vp, _i64],
     "lcm_set_tuning": [_i, _i, _i],
+    "lcm_set_split_policy": [_i, _i],
     "lcm_set_kernel_variant": [_i],
     "lcm_set_conv_impl": [_i],
     "lcm_set_persist_n": [_i],

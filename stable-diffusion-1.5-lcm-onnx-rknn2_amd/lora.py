@@ -12,8 +12,8 @@ key styles: kohya (``lora_unet_<path>.lora_down.weight`` / ``.lora_up.weight`` /
 encoders the same way (``ClipLora``), as ``pipe.load_lora_weights`` does for the reference.  LoCon entries on the
 ResnetBlock2D convolutions (conv1 / conv2 3x3: down [r,Cin,3,3] x up [Cout,r,1,1]; conv_shortcut 1x1), the resnets'
 time_emb_proj, and the down/upsampler convolutions are merged too, each delta packed the way its weight is (tap-major
-3x3 rows, the four-phase upsampler layout, the stacked time-embedding matrix).  conv_in / conv_out entries are
-reported and skipped.
+3x3 rows, the four-phase upsampler layout, the stacked time-embedding matrix), and so are entries on the UNet's conv_in /
+conv_out (tap-major rows, the layouts lcm_conv3x3_c4_f32in / lcm_conv3x3_smalln read).
 """
 from __future__ import annotations
 
@@ -26,7 +26,7 @@ from .packing import pack_conv1x1, pack_conv3x3, pack_conv3x3_up2, pack_geglu
 from .weights import unet_param_spec
 
 
-_CONV_TARGET = re.compile(r"\.resnets\.\d+\.(conv1|conv2|conv_shortcut|time_emb_proj)$|\.(downsamplers|upsamplers)\.0\.conv$")
+_CONV_TARGET = re.compile(r"\.resnets\.\d+\.(conv1|conv2|conv_shortcut|time_emb_proj)$|\.(downsamplers|upsamplers)\.0\.conv$|^conv_in$|^conv_out$")
 
 
 def _target_modules(cfg):
@@ -82,13 +82,26 @@ class LoraStyle:
         self.modules = sorted(parsed)
         deltas = {}
 
-        def acc(name, rows, d):
+        cdeltas = {}
+
+        def acc(name, rows, d, dc=None):
             w = unet.w[name]
             t = deltas.get(name)
             if t is None:
                 t = torch.zeros(w.shape, dtype=torch.float32)
                 deltas[name] = t
             t[rows[0]:rows[1]] += d
+            if dc is not None:           # LayerNorm-folded consumer: the delta of c = W beta + b that goes with it
+                c = cdeltas.setdefault(name, torch.zeros(w.shape[0], dtype=torch.float32))
+                c[rows[0]:rows[1]] += dc
+
+        def fold(name, d):
+            """A delta of a weight that carries a folded LayerNorm (model.UNetHip._put_ln_fold): columns scaled by gamma,
+            plus the matching delta of the constant c = W beta + b.  -> (delta of gamma (*) W, delta of c) or (d, None)."""
+            stem = name[:-2]
+            if (stem + ".lnw") not in unet.w:
+                return d, None
+            return d * unet.w[stem + ".lnw"].float().cpu()[None, :], d @ unet.w[stem + ".lnb"].float().cpu()
 
         for mod, (down, up, alpha) in parsed.items():
             if _CONV_TARGET.search(mod):
@@ -104,11 +117,11 @@ class LoraStyle:
             q, C = f"{p}.{k}", d.shape[0]
             if sub.startswith("attn1.to_") and sub[-1] in "qkv":
                 i = "qkv".index(sub[-1])
-                acc(q + ".qkv.w", (i * C, (i + 1) * C), d)
+                acc(q + ".qkv.w", (i * C, (i + 1) * C), *fold(q + ".qkv.w", d))
             elif sub == "attn1.to_out.0":
                 acc(q + ".o1.w", (0, C), d)
             elif sub == "attn2.to_q":
-                acc(q + ".q2.w", (0, C), d)
+                acc(q + ".q2.w", (0, C), *fold(q + ".q2.w", d))
             elif sub in ("attn2.to_k", "attn2.to_v"):
                 off, Ck = unet.kv_off[q]
                 o = off + (Ck if sub.endswith("v") else 0)
@@ -116,13 +129,17 @@ class LoraStyle:
             elif sub == "attn2.to_out.0":
                 acc(q + ".o2.w", (0, C), d)
             elif sub == "ff.net.0.proj":
-                dp, _ = pack_geglu(d, None)
-                acc(q + ".ff1.w", (0, dp.shape[0]), dp)
+                dg, dc = fold(q + ".ff1.w", d)
+                dp, dcp = pack_geglu(dg, dc)
+                acc(q + ".ff1.w", (0, dp.shape[0]), dp, dcp)
             elif sub == "ff.net.2":
                 acc(q + ".ff2.w", (0, C), d)
         dev = unet.device
         self.delta = {n: t.to(torch.float16).to(dev).contiguous() for n, t in deltas.items()}
         self.base = {n: unet.w[n].clone() for n in self.delta}
+        # LayerNorm-folded consumers touched by this style: their constants follow the live weight (ops.ln_fold_refresh)
+        self.cdelta = {n: t.to(dev).contiguous() for n, t in cdeltas.items()}
+        self.cbase = {n: unet.w[n[:-2] + ".c"].clone() for n in self.cdelta}
         self.current = 0.0
 
     @staticmethod
@@ -148,9 +165,12 @@ class LoraStyle:
         name = mod + ".w"
         packed = pack_conv3x3_up2(d4) if (".upsamplers." in mod and UPS_PHASES) else pack_conv3x3(d4)
         acc(name, (0, packed.shape[0]), packed)
+        if (mod + ".w3") in unet.w:               # the upsampler's plain 3x3 copy (odd-sized targets) follows the style too
+            p3 = pack_conv3x3(d4)
+            acc(mod + ".w3", (0, p3.shape[0]), p3)
 
     def nbytes(self):
-        return 2 * sum(t.numel() * 2 for t in self.delta.values())
+        return 2 * sum(t.numel() * 2 for t in self.delta.values()) + 2 * sum(t.numel() * 4 for t in self.cdelta.values())
 
     def apply(self, weight: float):
         weight = float(weight)
@@ -158,6 +178,10 @@ class LoraStyle:
             return
         for n, d in self.delta.items():
             ops.axpy(self.base[n], d, weight, self.unet.w[n])
+            if n in self.cdelta:
+                stem = n[:-2]
+                ops.ln_fold_refresh(self.unet.w[n], self.unet.w[stem + ".g"], self.cbase[n], self.cdelta[n], weight,
+                                    self.unet.w[stem + ".c"])
         self.current = weight
 
 

@@ -28,6 +28,9 @@ UPS_PHASES = os.environ.get("LCM_UPS_PHASES", "1") != "0"
 # 128) and a tensor too large for the Infinity Cache, so that the separate pass really is HBM time (in situ the apply pass
 # reads what the producer just wrote: below ~64 MB it is served from MALL and fusing gains nothing; measured +1.5 % at
 # batch 8 and +0.2 % at batch 1 with the VAE's 512^2 / 256^2 levels fused; tools/gn_fuse_bench.py has the cold numbers)
+# LayerNorm folded into the GEMM that consumes it (norm1 -> q|k|v, norm2 -> attn2.to_q, norm3 -> GEGLU proj): 192 launches
+# fewer per 512x512 4-step pass, no LayerNorm output in HBM (ops.gemm_ln / lcm_gemm_ln_f16)
+LN_FOLD = os.environ.get("LCM_LN_FOLD", "1") != "0"
 FUSE_GN_CONV = os.environ.get("LCM_FUSE_GN_CONV", "1") != "0"
 FUSE_GN_MIN_BYTES = int(os.environ.get("LCM_FUSE_GN_MIN_BYTES", str(64 << 20)))
 
@@ -70,6 +73,15 @@ class _Net:
 
     def _put(self, name, t, dtype=torch.float16):
         self.w[name] = _dev(t, self.device, dtype)
+
+    def view(self):
+        """The same network (shared weight tensors: a style re-merge reaches every view) with scratch of its own -- one per
+        pipeline lane, so two captured passes can be in flight at once without sharing an activation buffer."""
+        v = object.__new__(type(self))
+        v.__dict__.update(self.__dict__)
+        v.buf = _Buffers(self.device)
+        v._stats = {}
+        return v
 
     def stats(self, role, M, C, hw):
         """Per-role holder of the producer-written GroupNorm statistics of an [M, C] tensor of M // hw images."""
@@ -199,6 +211,8 @@ class UNetHip(_Net):
             if i < nb - 1:
                 p = f"up_blocks.{i}.upsamplers.0.conv"
                 self._put(p + ".w", (pack_conv3x3_up2 if UPS_PHASES else pack_conv3x3)(sd[p + ".weight"]))
+                if UPS_PHASES:       # plain 3x3 layout too: upsampling to an odd-sized skip cannot use the pre-summed phase weights
+                    self._put(p + ".w3", pack_conv3x3(sd[p + ".weight"]))
                 self._put(p + ".b", sd[p + ".bias"])
         self._put("conv_norm_out.g", sd["conv_norm_out.weight"])
         self._put("conv_norm_out.b", sd["conv_norm_out.bias"])
@@ -220,6 +234,22 @@ class UNetHip(_Net):
         self.kv_total = off
         self._put("kv_all.w", torch.cat([torch.cat([wk, wv], 0) for _, wk, wv in kv_list], 0))
 
+    def _put_ln_fold(self, name, W, b, gamma, beta, geglu=False):
+        """Weights of LayerNorm(gamma, beta) -> Linear(W, b) as one contraction (ops.gemm_ln):
+        ``name.w`` = gamma (*) W (fp16, GEGLU rows interleaved), ``name.g`` = its fp32 row sums, ``name.c`` = W beta + b (fp32).
+        The fp32 per-column scale ``name.lnw`` / shift ``name.lnb`` stay around for the style-LoRA re-merge (lora.py)."""
+        Wf, g32, b32 = W.float(), gamma.float(), beta.float()
+        Wg = Wf * g32[None, :]
+        c = Wf @ b32 + (b.float() if b is not None else 0.0)
+        if geglu:
+            Wg, c = pack_geglu(Wg, c)
+        Wh = Wg.to(torch.float16)
+        self._put(name + ".w", Wh)
+        self._put(name + ".g", Wh.float().sum(1), torch.float32)
+        self._put(name + ".c", c, torch.float32)
+        self._put(name + ".lnw", g32, torch.float32)
+        self._put(name + ".lnb", b32, torch.float32)
+
     def _pack_transformer(self, sd, p, kv_list, depth=1):
         self._put(p + ".norm.g", sd[p + ".norm.weight"])
         self._put(p + ".norm.b", sd[p + ".norm.bias"])
@@ -232,16 +262,23 @@ class UNetHip(_Net):
             for n in ("norm1", "norm2", "norm3"):
                 self._put(f"{q}.{n}.g", sd[f"{t}.{n}.weight"])
                 self._put(f"{q}.{n}.b", sd[f"{t}.{n}.bias"])
-            self._put(q + ".qkv.w", torch.cat([sd[f"{t}.attn1.to_{n}.weight"] for n in "qkv"], 0))
+            wqkv = torch.cat([sd[f"{t}.attn1.to_{n}.weight"] for n in "qkv"], 0)
+            wq2, wff, bff = sd[f"{t}.attn2.to_q.weight"], sd[f"{t}.ff.net.0.proj.weight"], sd[f"{t}.ff.net.0.proj.bias"]
+            if LN_FOLD:
+                self._put_ln_fold(q + ".qkv", wqkv, None, sd[f"{t}.norm1.weight"], sd[f"{t}.norm1.bias"])
+                self._put_ln_fold(q + ".q2", wq2, None, sd[f"{t}.norm2.weight"], sd[f"{t}.norm2.bias"])
+                self._put_ln_fold(q + ".ff1", wff, bff, sd[f"{t}.norm3.weight"], sd[f"{t}.norm3.bias"], geglu=True)
+            else:
+                self._put(q + ".qkv.w", wqkv)
+                self._put(q + ".q2.w", wq2)
+                wp, bp = pack_geglu(wff, bff)
+                self._put(q + ".ff1.w", wp)
+                self._put(q + ".ff1.b", bp)
             self._put(q + ".o1.w", sd[f"{t}.attn1.to_out.0.weight"])
             self._put(q + ".o1.b", sd[f"{t}.attn1.to_out.0.bias"])
-            self._put(q + ".q2.w", sd[f"{t}.attn2.to_q.weight"])
             self._put(q + ".o2.w", sd[f"{t}.attn2.to_out.0.weight"])
             self._put(q + ".o2.b", sd[f"{t}.attn2.to_out.0.bias"])
             kv_list.append((q, sd[f"{t}.attn2.to_k.weight"], sd[f"{t}.attn2.to_v.weight"]))
-            wp, bp = pack_geglu(sd[f"{t}.ff.net.0.proj.weight"], sd[f"{t}.ff.net.0.proj.bias"])
-            self._put(q + ".ff1.w", wp)
-            self._put(q + ".ff1.b", bp)
             self._put(q + ".ff2.w", sd[f"{t}.ff.net.2.weight"])
             self._put(q + ".ff2.b", sd[f"{t}.ff.net.2.bias"])
 
@@ -299,19 +336,28 @@ class UNetHip(_Net):
         ff = self.buf.get("tf_ff", M, 4 * C)
         for k in range(depth):
             q = f"{p}.{k}"
-            ops.layernorm(h, w[q + ".norm1.g"], w[q + ".norm1.b"], n, M, C)
-            ops.gemm(n, w[q + ".qkv.w"], qkv, img_rows=HW)
+            if LN_FOLD:
+                ops.gemm_ln(h, w[q + ".qkv.w"], w[q + ".qkv.g"], w[q + ".qkv.c"], qkv, img_rows=HW)
+            else:
+                ops.layernorm(h, w[q + ".norm1.g"], w[q + ".norm1.b"], n, M, C)
+                ops.gemm(n, w[q + ".qkv.w"], qkv, img_rows=HW)
             ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], a, B, heads, HW, HW, d, ldq=3 * C, ldk=3 * C,
                           ldv=3 * C, ldo=C)
             ops.gemm(a, w[q + ".o1.w"], h, bias=w[q + ".o1.b"], res=h, img_rows=HW)
-            ops.layernorm(h, w[q + ".norm2.g"], w[q + ".norm2.b"], n, M, C)
-            ops.gemm(n, w[q + ".q2.w"], q2, img_rows=HW)
+            if LN_FOLD:
+                ops.gemm_ln(h, w[q + ".q2.w"], w[q + ".q2.g"], w[q + ".q2.c"], q2, img_rows=HW)
+            else:
+                ops.layernorm(h, w[q + ".norm2.g"], w[q + ".norm2.b"], n, M, C)
+                ops.gemm(n, w[q + ".q2.w"], q2, img_rows=HW)
             off, _ = self.kv_off[q]
             ops.attention(q2, kv_all[:, off:off + C], kv_all[:, off + C:off + 2 * C], a, B, heads, HW, TEXT_SEQ_LEN, d,
                           ldq=C, ldk=self.kv_total, ldv=self.kv_total, ldo=C)
             ops.gemm(a, w[q + ".o2.w"], h, bias=w[q + ".o2.b"], res=h, img_rows=HW)
-            ops.layernorm(h, w[q + ".norm3.g"], w[q + ".norm3.b"], n, M, C)
-            ops.gemm(n, w[q + ".ff1.w"], ff, bias=w[q + ".ff1.b"], epilogue=1, img_rows=HW)
+            if LN_FOLD:
+                ops.gemm_ln(h, w[q + ".ff1.w"], w[q + ".ff1.g"], w[q + ".ff1.c"], ff, epilogue=1, img_rows=HW)
+            else:
+                ops.layernorm(h, w[q + ".norm3.g"], w[q + ".norm3.b"], n, M, C)
+                ops.gemm(n, w[q + ".ff1.w"], ff, bias=w[q + ".ff1.b"], epilogue=1, img_rows=HW)
             ops.gemm(ff, w[q + ".ff2.w"], h, bias=w[q + ".ff2.b"], res=h, img_rows=HW)
         out = self.buf.get(out_role, M, C)
         out_st = self.stats(out_role, M, C, HW)
@@ -387,8 +433,11 @@ class UNetHip(_Net):
                 Ho, Wo = sizes[nb - 2 - i]
                 y = self.buf.get("ups", B * Ho * Wo, ch)
                 st = self.stats("ups", B * Ho * Wo, ch, Ho * Wo)
-                ops.conv3x3(x, wt[p + ".w"], y, B, H, W, ch, ch, bias=wt[p + ".b"], ups=2 if UPS_PHASES else 1, stats=st,
-                            out_hw=(Ho, Wo))
+                if (Ho, Wo) == (2 * H, 2 * W):
+                    ops.conv3x3(x, wt[p + ".w"], y, B, H, W, ch, ch, bias=wt[p + ".b"], ups=2 if UPS_PHASES else 1, stats=st)
+                else:                # odd target: the conv pads the CROPPED upsampled image with zeros -> loader-fused form
+                    ops.conv3x3(x, wt[p + (".w3" if UPS_PHASES else ".w")], y, B, H, W, ch, ch, bias=wt[p + ".b"], ups=1,
+                                stats=st, out_hw=(Ho, Wo))
                 H, W, x = Ho, Wo, y
                 tap(f"up_blocks.{i}.upsamplers.0", x, ch, H, W)
         hn = self.buf.get("gn", B * H * W, ch)

@@ -140,16 +140,40 @@ def gemm(a, w, out, *, bias=None, res=None, rowadd=None, rows_per_batch=0, a2=No
     return out
 
 
+def gemm_ln(a, w, ln_g, ln_c, out, *, eps=1e-5, epilogue=0, img_rows=0):
+    """out = LayerNorm(a) W^T + b with the LayerNorm folded into the contraction (include/lcm_hip.h, lcm_gemm_ln_f16):
+    w = gamma (*) W fp16 [N, K], ln_g / ln_c fp32 [N]."""
+    L = _lib.load()
+    M, K = a.shape
+    N = w.shape[0]
+    if RECORD is not None:
+        RECORD.append(((0, M, N, K, 1), dict(halo=False, geglu=(epilogue == 1), m_img=(img_rows if img_rows and M % img_rows == 0 else M),
+                                             splittable=False),
+                       lambda: gemm_ln(a, w, ln_g, ln_c, out, eps=eps, epilogue=epilogue, img_rows=img_rows)))
+    with _Timed("gemm", "", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N)):
+        rc = L.lcm_gemm_ln_f16(_p(a), a.stride(0), _p(w), _p(ln_g), _p(ln_c), float(eps), _p(out), out.stride(0), M, N, K,
+                               int(epilogue), int(img_rows), _stream())
+    _lib.check(rc, "lcm_gemm_ln_f16")
+    return out
+
+
+def ln_fold_refresh(w, g_out, c_base=None, c_delta=None, alpha=0.0, c_out=None):
+    _lib.check(_lib.load().lcm_ln_fold_refresh(_p(w), w.shape[0], w.shape[1], _p(c_base), _p(c_delta), float(alpha), _p(g_out),
+                                               _p(c_out), _stream()), "lcm_ln_fold_refresh")
+
+
 def conv3x3(x, w, out, B, H, W, Cin, Cout, *, bias=None, rowadd=None, res=None, stride=1, ups=0, stats=None, out_hw=None):
     """out_hw: (Ho, Wo) of an upsampling conv whose target is the odd-sized skip tensor (2H-1 / 2W-1): Upsample2D called
-    with output_size, F.interpolate(size=..., mode="nearest") == the 2x result cropped by one row / column."""
+    with output_size; F.interpolate(size=..., mode="nearest") is the 2x result cropped by one row / column, and the conv
+    then pads THAT with zeros -- so only the loader-fused form (ups=1, plain 3x3 weights) can serve it."""
     L = _lib.load()
     sbuf, sp = _stats_args(stats)
     Ho, Wo = ((2 * H, 2 * W) if ups else ((H + 1) // 2, (W + 1) // 2) if stride == 2 else (H, W))
     flags = ups
     if out_hw is not None and tuple(out_hw) != (Ho, Wo):
-        if not ups or out_hw[0] not in (2 * H, 2 * H - 1) or out_hw[1] not in (2 * W, 2 * W - 1):
-            raise _lib.LcmHipError(f"conv3x3: output size {tuple(out_hw)} is not reachable from {H}x{W} (ups={ups})")
+        if ups != 1 or out_hw[0] not in (2 * H, 2 * H - 1) or out_hw[1] not in (2 * W, 2 * W - 1):
+            raise _lib.LcmHipError(f"conv3x3: output size {tuple(out_hw)} from {H}x{W} needs ups=1 (plain 3x3 weights) and 2n / 2n-1 "
+                                   f"targets, got ups={ups}")
         flags = ups | (4 if out_hw[0] == 2 * H - 1 else 0) | (8 if out_hw[1] == 2 * W - 1 else 0)
         Ho, Wo = out_hw
     Mo = B * Ho * Wo
@@ -337,8 +361,19 @@ def set_workspace(t):
     _lib.check(L.lcm_set_workspace(_p(t), 0 if t is None else t.numel() * t.element_size()), "lcm_set_workspace")
 
 
+def set_stream_workspace(stream, t):
+    """A split-K workspace of its own for the launches of ``stream`` (a torch.cuda.Stream); None forgets it."""
+    L = _lib.load()
+    _lib.check(L.lcm_set_stream_workspace(C.c_void_p(stream.cuda_stream), _p(t), 0 if t is None else t.numel() * t.element_size()),
+               "lcm_set_stream_workspace")
+
+
 def set_tuning(target_wgs=0, max_splits=0, min_wgs=0):
     _lib.check(_lib.load().lcm_set_tuning(int(target_wgs), int(max_splits), int(min_wgs)), "lcm_set_tuning")
+
+
+def set_split_policy(max_rows_per_image=1024, max_parts=4):
+    _lib.check(_lib.load().lcm_set_split_policy(int(max_rows_per_image), int(max_parts)), "lcm_set_split_policy")
 
 
 def set_gn_fused_bytes(n):

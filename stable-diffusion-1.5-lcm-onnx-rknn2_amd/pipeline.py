@@ -12,6 +12,7 @@ launched, so the captured graph is RNG-free and replays for any seed.
 from __future__ import annotations
 
 import os
+import threading
 
 import numpy as np
 import torch
@@ -54,24 +55,42 @@ def draw_noise(seed: int, h: int, w: int, n_extra: int, sigma: float = 1.0):
 _WS = {}
 
 
-def _splitk_workspace(device):
-    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+def _splitk_workspace(device, lane=0):
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device(), lane)
     t = _WS.get(key)
     if t is None:
-        # sized for a batch of 8 at 512x512 / SDXL 1024x1024 batch 1 (fp32 [splits][M][N] of the largest split layer); a launch
+        # sized for a batch of 8 at 768x768 (472 MB) / SDXL 1024x1024 (fp32 [splits][M][N] of the largest split layer); a launch
         # that needs more fails loudly (a silently smaller split factor would change the numbers)
-        t = torch.empty(int(os.environ.get("LCM_SPLITK_WS_MB", "384")) << 18, dtype=torch.float32, device=device)
+        t = torch.empty(int(os.environ.get("LCM_SPLITK_WS_MB", "1024")) << 18, dtype=torch.float32, device=device)
         _WS[key] = t
     return t
+
+
+class _Lane:
+    """One sampler instance of a pipeline: a stream, executors with scratch of their own (weights shared), its plans /
+    captured graphs and its split-K workspace.  Lanes of one pipeline run concurrently: a single batch-1 pass is a
+    chain of ~1700 latency-bound launches that leaves a third of the MI355X idle, so two requests in flight on two
+    lanes finish in less than twice the time of one."""
+
+    def __init__(self, pipe, index, unet, vae):
+        self.index = index
+        self.unet, self.vae = unet, vae
+        self.stream = torch.cuda.Stream(device=pipe.device)
+        self.plans = {}
+        # The library keeps raw workspace pointers (per stream / per device): the tensors are process-lifetime singletons
+        # per (device, lane) and outlive every pipeline / captured graph that may still launch with them.
+        self.splitk_ws = _splitk_workspace(pipe.device, index)
+        ops.set_stream_workspace(self.stream, self.splitk_ws)
 
 
 class _Plan:
     """Buffers + captured graph for one (B, h, w, steps, cfg) key."""
 
-    def __init__(self, pipe, B, h, w, steps, do_cfg):
-        # Every zero-fill below must be ordered before the first use on the pipeline's (non-blocking) stream: allocate
+    def __init__(self, pipe, B, h, w, steps, do_cfg, lane=None):
+        # Every zero-fill below must be ordered before the first use on the lane's (non-blocking) stream: allocate
         # under that stream, or a fill still queued on the null stream can land AFTER the request's uploads.
-        with torch.cuda.stream(pipe.stream):
+        self.lane = lane if lane is not None else pipe.lanes[0]
+        with torch.cuda.stream(self.lane.stream):
             self._init(pipe, B, h, w, steps, do_cfg)
 
     def _init(self, pipe, B, h, w, steps, do_cfg):
@@ -112,13 +131,14 @@ class LcmHipPipeline:
         self.vae = VAEDecoderHip(vae_sd, vae_cfg, self.device)
         self.sched = schedule or LCMSchedule()
         self.use_graph = use_graph
-        self._plans = {}
         self._tuned_keys = set()
-        self.stream = torch.cuda.Stream(device=self.device)
-        # fp32 scratch for deterministic split-K of the deep-K / small-M layers (low-res UNet levels at batch 1).
-        # The library keeps the raw pointer per device, so the tensor is a process-lifetime singleton per device:
-        # it must outlive every pipeline / captured graph that may still launch with it.
-        self._splitk_ws = _splitk_workspace(self.device)
+        self._build_lock = threading.RLock()      # tuning / eager warm-up / capture of a plan: one lane at a time
+        self.lanes = [_Lane(self, 0, self.unet, self.vae)]
+        self.stream = self.lanes[0].stream
+        self._plans = self.lanes[0].plans
+        # fp32 scratch for deterministic split-K of the deep-K / small-M layers (low-res UNet levels at batch 1):
+        # lane 0's is also the device-wide default (eager launches on other streams, e.g. tests).
+        self._splitk_ws = self.lanes[0].splitk_ws
         ops.set_workspace(self._splitk_ws)
         if "LCM_CONV_IMPL" in os.environ:            # A/B switches for kernel work
             ops.set_conv_impl(int(os.environ["LCM_CONV_IMPL"]))
@@ -132,20 +152,28 @@ class LcmHipPipeline:
             ops.set_kernel_variant(int(os.environ["LCM_KERNEL_VARIANT"]))
 
     # ------------------------------------------------------------------------------------------
+    def lane(self, index: int) -> _Lane:
+        """Lane ``index`` (created on first use: executor views + stream + workspace; weights are shared)."""
+        with self._build_lock:
+            while len(self.lanes) <= index:
+                self.lanes.append(_Lane(self, len(self.lanes), self.unet.view(), self.vae.view()))
+        return self.lanes[index]
+
     def _enqueue(self, P: _Plan, guidance: float, want_float=False, taps=None):
         """Enqueue the whole sampler on the current stream (this is what gets captured)."""
         B, UB, h, w = P.B, P.UB, P.h, P.w
+        unet, vae = P.lane.unet, P.lane.vae
         ts = self.sched.timesteps(P.steps)
         if P.do_cfg:
             P.lat[:B].copy_(P.lat0)
             P.lat[B:].copy_(P.lat0)
         else:
             P.lat.copy_(P.lat0)
-        kv = self.unet.encode_context(P.ehs, UB)
-        aug = self.unet.encode_added(P.add_in, UB) if self.unet.has_added else None
-        wemb = P.wemb if self.unet.has_cond else None
+        kv = unet.encode_context(P.ehs, UB)
+        aug = unet.encode_added(P.add_in, UB) if unet.has_added else None
+        wemb = P.wemb if unet.has_cond else None
         for i, t in enumerate(ts):
-            self.unet.forward(P.lat, int(t), kv, wemb, UB, h, w, P.eps, taps=taps if i == 0 else None, aug=aug)
+            unet.forward(P.lat, int(t), kv, wemb, UB, h, w, P.eps, taps=taps if i == 0 else None, aug=aug)
             coef, last = self.sched.step_coefficients(ts, i)
             noise = P.noise[min(i, P.noise.shape[0] - 1)]
             if P.do_cfg:   # rows [0,B) = negative prompt, [B,2B) = prompt
@@ -157,16 +185,20 @@ class LcmHipPipeline:
         ops.latents_pool8(final, P.pool8, B, h, w)
         if want_float and P.img_f32 is None:
             P.img_f32 = torch.zeros(B, h * 8, w * 8, 3, dtype=torch.float32, device=self.device)
-        self.vae.decode(final, B, h, w, P.rgb, img_f32=P.img_f32 if want_float else None, taps=taps)
+        vae.decode(final, B, h, w, P.rgb, img_f32=P.img_f32 if want_float else None, taps=taps)
         return final
 
-    def plan(self, B, h, w, steps, do_cfg=False, guidance=None) -> _Plan:
+    def plan(self, B, h, w, steps, do_cfg=False, guidance=None, lane=0) -> _Plan:
         # classifier-free guidance bakes the guidance value into the captured step kernels: one plan per value
         key = (B, h, w, steps, do_cfg, round(float(guidance), 4) if do_cfg and guidance is not None else None)
-        P = self._plans.get(key)
+        L = self.lane(lane)
+        P = L.plans.get(key)
         if P is None:
-            P = _Plan(self, B, h, w, steps, do_cfg)
-            self._plans[key] = P
+            with self._build_lock:
+                P = L.plans.get(key)
+                if P is None:
+                    P = _Plan(self, B, h, w, steps, do_cfg, L)
+                    L.plans[key] = P
         return P
 
     def tune(self, P: _Plan, verbose=False):
@@ -174,37 +206,43 @@ class LcmHipPipeline:
         if os.environ.get("LCM_AUTOTUNE", "1") == "0" or getattr(P, "tuned", False):
             return
         from . import autotune
-        with torch.cuda.stream(self.stream):
+        stream = P.lane.stream
+        with self._build_lock, torch.cuda.stream(stream):
             self._enqueue(P, 1.0)                    # allocate scratch, warm caches
             ops.RECORD = []
             try:
                 self._enqueue(P, 1.0)
             finally:
                 recs, ops.RECORD = ops.RECORD, None
-            self.stream.synchronize()
+            stream.synchronize()
             todo = [r for r in recs if r[0] is not None and r[0] not in self._tuned_keys]
             # in situ every layer's weights come from HBM and its input was written by the previous kernel, never by a
             # previous run of the same layer: time the candidates with cold caches (autotune._time_cold); measured
             # +2.5 % at batch 1 and +1.7 % at batch 8 over warm back-to-back timing.  LCM_AUTOTUNE_COLD=0: warm timing
             cold = os.environ.get("LCM_AUTOTUNE_COLD", "1") != "0"
-            res = autotune.autotune(todo, self._splitk_ws.numel() * 4, verbose=verbose, cold=cold)
+            # LCM_TUNE_SPLITS=1: offline table generation only (tools/make_plans.py) -- a serving process never times splits
+            res = autotune.autotune(todo, P.lane.splitk_ws.numel() * 4, verbose=verbose, cold=cold,
+                                    tune_splits=os.environ.get("LCM_TUNE_SPLITS", "0") == "1")
             self._tuned_keys.update(res.keys())
-            self.stream.synchronize()
+            stream.synchronize()
         P.tuned = True
 
     def drop_plans(self):
-        for P in self._plans.values():
-            if P.graph is not None:
-                P.graph.close()
-        self._plans.clear()
+        for L in self.lanes:
+            for P in L.plans.values():
+                if P.graph is not None:
+                    P.graph.close()
+            L.plans.clear()
 
     # ------------------------------------------------------------------------------------------
     @torch.inference_mode()
     def generate(self, prompt_embeds, seeds, width, height, steps, guidance_scale=1.0, negative_embeds=None,
-                 want_float=False, taps=None, latents=None, added=None, negative_added=None, noises=None):
+                 want_float=False, taps=None, latents=None, added=None, negative_added=None, noises=None, lane=0):
         """prompt_embeds: [B,77,ctx] (any float dtype, host or device); seeds: B ints.  noises: optional per-request
         ``draw_noise(seed, h, w, steps - 1, init_noise_sigma)`` results drawn ahead by the callers (the worker's pool
         threads draw them in parallel, off the dispatcher's serial path); None: drawn here from the seeds.
+        lane: which of the pipeline's concurrent sampler instances runs the request (calls on different lanes may overlap;
+        calls on one lane must be serialised by the caller).
         Returns dict(rgb uint8 [B,H,W,3] (host), latents fp32 [B,4,h,w] (host), pool8 fp16 [B,4,8,8] (host))."""
         torch.cuda.set_device(self.device)        # the pool may call from a thread other than the constructing one
         pe = torch.as_tensor(prompt_embeds)
@@ -221,8 +259,9 @@ class LcmHipPipeline:
             raise LcmHipError("classifier-free guidance needs negative_embeds")
         if self.unet.has_added and added is None:
             raise LcmHipError("this UNet needs added=(pooled_text_embeds [B,P], time_ids [B,6]) (SDXL text_time embedding)")
-        P = self.plan(B, h, w, steps, do_cfg, guidance_scale)
-        with torch.cuda.stream(self.stream):
+        P = self.plan(B, h, w, steps, do_cfg, guidance_scale, lane=lane)
+        stream = P.lane.stream
+        with torch.cuda.stream(stream):
             # ---- host-side request state -> device (outside the graph) ----
             for b, s in enumerate(seeds):
                 if latents is not None:
@@ -262,22 +301,25 @@ class LcmHipPipeline:
             # ---- the sampler: eager once (allocates scratch), then captured + replayed ----
             eager = (not self.use_graph) or taps is not None or want_float
             if eager:
-                final = self._enqueue(P, guidance_scale, want_float=want_float, taps=taps)
+                with self._build_lock:               # eager launches allocate scratch and read ops.RECORD / PROFILE
+                    final = self._enqueue(P, guidance_scale, want_float=want_float, taps=taps)
             else:
                 if P.graph is None:
-                    self.tune(P)
-                    self._enqueue(P, guidance_scale)           # warm-up: allocates every scratch buffer
-                    self.stream.synchronize()
-                    g = ops.Graph()
-                    with g:
-                        self._enqueue(P, guidance_scale)
-                    P.graph = g
+                    with self._build_lock:
+                        if P.graph is None:
+                            self.tune(P)
+                            self._enqueue(P, guidance_scale)           # warm-up: allocates every scratch buffer
+                            stream.synchronize()
+                            g = ops.Graph()
+                            with g:
+                                self._enqueue(P, guidance_scale)
+                            P.graph = g
                 P.graph.launch()
                 final = P.lat[B:] if do_cfg else P.lat
             P.h_rgb.copy_(P.rgb, non_blocking=True)
             P.h_pool8.copy_(P.pool8, non_blocking=True)
             P.h_latout.copy_(final, non_blocking=True)
-            self.stream.synchronize()
+            stream.synchronize()
         out = dict(rgb=P.h_rgb.numpy().copy(), latents=P.h_latout.numpy().copy(), pool8=P.h_pool8.numpy().copy())
         if want_float:
             out["image"] = P.img_f32.cpu().numpy()   # NHWC float, pre-clamp

@@ -169,21 +169,25 @@ def test_lora_key_parsing_kohya_and_peft():
         # peft / diffusers naming
         "unet.up_blocks.1.attentions.2.transformer_blocks.0.attn2.to_k.lora_A.weight": torch.randn(r, 96),
         "unet.up_blocks.1.attentions.2.transformer_blocks.0.attn2.to_k.lora_B.weight": torch.randn(128, r),
-        # text encoder entries are not the UNet parser's (lora.ClipLora takes them); conv_in is not a target
+        # text encoder entries are not the UNet parser's (lora.ClipLora takes them); conv_in IS a target, but this
+        # entry has no lora_up partner, so it is matched and then dropped as incomplete
         "lora_te_text_model_encoder_layers_0_mlp_fc1.lora_down.weight": torch.randn(r, 768),
         "lora_unet_conv_in.lora_down.weight": torch.randn(r, 4, 3, 3),
+        "lora_unet_conv_out.lora_down.weight": torch.randn(r, 64, 3, 3),
+        "lora_unet_conv_out.lora_up.weight": torch.randn(4, r, 1, 1),
         # LoCon on a resnet conv: 3x3 extent on lora_down, 1x1 lora_up
         "lora_unet_down_blocks_0_resnets_0_conv1.lora_down.weight": torch.randn(r, 64, 3, 3),
         "lora_unet_down_blocks_0_resnets_0_conv1.lora_up.weight": torch.randn(64, r, 1, 1),
     }
     parsed, skipped = parse_lora(raw, cfg)
     assert set(parsed) == {"down_blocks.0.attentions.1.transformer_blocks.0.attn1.to_q", "mid_block.attentions.0.proj_in",
-                           "up_blocks.1.attentions.2.transformer_blocks.0.attn2.to_k", "down_blocks.0.resnets.0.conv1"}
+                           "up_blocks.1.attentions.2.transformer_blocks.0.attn2.to_k", "down_blocks.0.resnets.0.conv1", "conv_out"}
+    assert parsed["conv_out"][0].shape == (r, 64, 3, 3) and parsed["conv_out"][1].shape == (4, r)
     assert parsed["down_blocks.0.resnets.0.conv1"][0].shape == (r, 64, 3, 3) and parsed["down_blocks.0.resnets.0.conv1"][1].shape == (64, r)
     d, u, a = parsed["down_blocks.0.attentions.1.transformer_blocks.0.attn1.to_q"]
     assert d.shape == (r, 64) and u.shape == (64, r) and a == 2.0
     assert parsed["mid_block.attentions.0.proj_in"][0].shape == (r, 128) and parsed["mid_block.attentions.0.proj_in"][2] == float(r)
-    assert len(skipped) == 2
+    assert len(skipped) == 1
 
 
 def test_style_registry_mirror():

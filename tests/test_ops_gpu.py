@@ -823,23 +823,30 @@ def test_split_workspace_too_small_fails_loudly():
 # ----------------------------------------------------------------------------------------------
 # Request sizes that are multiples of 8 but not of 64 (backends/rknnlcm.py:380-381; the UI ships 640x360).
 # ----------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("B,H,W,Cin,Cout,oh,ow,phase", [(1, 7, 12, 128, 128, 13, 24, True), (2, 13, 9, 64, 128, 25, 17, True),
-                                                      (1, 12, 23, 128, 64, 23, 45, True), (1, 7, 12, 128, 128, 13, 23, False),
-                                                      (1, 25, 33, 320, 320, 49, 65, True)])
-def test_conv_upsample_to_odd_skip_size(B, H, W, Cin, Cout, oh, ow, phase):
-    """Upsample2D with output_size = an odd-sized skip (2H-1 / 2W-1): F.interpolate(size=..., mode="nearest") -> conv3x3,
-    as the phase-decomposed conv (and the loader-fused form) with the last output row / column cropped; fused statistics
-    of the cropped output included."""
-    from sdlcm_amd.packing import pack_conv3x3_up2
+@pytest.mark.parametrize("B,H,W,Cin,Cout,oh,ow", [(1, 7, 12, 128, 128, 13, 24), (2, 13, 9, 64, 128, 25, 17), (1, 12, 23, 128, 64, 23, 45),
+                                                (1, 7, 12, 128, 128, 13, 23), (1, 25, 33, 320, 320, 49, 65), (1, 7, 9, 1280, 1280, 13, 17)])
+def test_conv_upsample_to_odd_skip_size(B, H, W, Cin, Cout, oh, ow):
+    """Upsample2D with output_size = an odd-sized skip (2H-1 / 2W-1): F.interpolate(size=..., mode="nearest") -> conv3x3.
+    The conv pads the cropped upsampled image with zeros, so the border outputs see fewer taps than the pre-summed phase
+    weights hold: the loader-fused form (ups=1, plain 3x3 weights) serves it, the phase form must refuse.  Fused
+    statistics of the output included (split-K reduce slabs of an odd-sized image in the 1280-channel case)."""
+    from sdlcm_amd.lib import LcmHipError
     x4 = rnd(B, Cin, H, W, seed=1)
     w4 = rnd(Cout, Cin, 3, 3, seed=2, scale=(9 * Cin) ** -0.5)
     b = rnd(Cout, seed=3)
     ref = F.conv2d(F.interpolate(x4.float(), size=(oh, ow), mode="nearest"), w4.float(), b.float(), padding=1)
-    wk = (pack_conv3x3_up2(w4) if phase else pack3x3(w4)).to(DEV)
+    wk = pack3x3(w4).to(DEV)
     o = torch.empty(B * oh * ow, Cout, dtype=torch.float16, device=DEV)
     st = ops.Stats(torch.zeros(ops.stats_floats(B * oh * ow, Cout, oh * ow), dtype=torch.float32, device=DEV))
-    ops.conv3x3(to_nhwc(x4).to(DEV), wk, o, B, H, W, Cin, Cout, bias=b.to(DEV), ups=2 if phase else 1, stats=st, out_hw=(oh, ow))
-    torch.cuda.synchronize()
+    skws = torch.empty(16 << 20, dtype=torch.float32, device=DEV)
+    ops.set_workspace(skws)
+    try:
+        with pytest.raises(LcmHipError):
+            ops.conv3x3(to_nhwc(x4).to(DEV), wk, o, B, H, W, Cin, Cout, bias=b.to(DEV), ups=2, out_hw=(oh, ow))
+        ops.conv3x3(to_nhwc(x4).to(DEV), wk, o, B, H, W, Cin, Cout, bias=b.to(DEV), ups=1, stats=st, out_hw=(oh, ow))
+        torch.cuda.synchronize()
+    finally:
+        ops.set_workspace(None)
     close(from_nhwc(o, B, oh, ow), ref, what="upsample conv to odd size")
     assert st.P > 0
     gamma, beta = (1 + 0.1 * rnd(Cout, seed=4).float()).half(), rnd(Cout, seed=5, scale=0.1)
@@ -856,3 +863,86 @@ def test_softmax_ragged_rows_zero_padding(rows, n, ld):
     got = x.float().cpu()
     assert (got[:, n:] == 0).all()
     assert (got[:, :n] - ref).abs().max() < 2e-3
+
+
+@pytest.mark.parametrize("B,H,W,C1,C2,Cout", [(1, 16, 16, 1280, 640, 1280), (2, 32, 32, 640, 320, 640), (1, 64, 64, 128, 0, 128),
+                                             (1, 24, 24, 320, 320, 320)])
+def test_gn_fused_conv_is_bit_identical_to_apply_then_conv(B, H, W, C1, C2, Cout):
+    """GroupNorm+SiLU applied while the conv stages its halo (chosen from the TOTAL tensor size, so from the batch) must give
+    the bits of the separate apply pass followed by the plain conv: same affine, same fp16 rounding of the normalised
+    value, same K partition (split-K included: the 16x16 and 32x32 cases split)."""
+    C = C1 + C2
+    x1 = to_nhwc(rnd(B, C1, H, W, seed=1) * 1.5 + 0.3).to(DEV)
+    x2 = to_nhwc(rnd(B, C2, H, W, seed=2) * 0.7 - 0.5).to(DEV) if C2 else None
+    gamma, beta = (1 + 0.1 * rnd(C, seed=3).float()).half().to(DEV), rnd(C, seed=4, scale=0.1).to(DEV)
+    w = pack3x3(rnd(Cout, C, 3, 3, seed=5, scale=(9 * C) ** -0.5)).to(DEV)
+    b, radd = rnd(Cout, seed=6).to(DEV), rnd(B, Cout, seed=7).to(DEV)
+    HW = H * W
+    ws = torch.empty(ops.groupnorm_ws_bytes(B, HW, C) // 4 + 16, dtype=torch.float32, device=DEV)
+    scale = torch.empty(B, C, dtype=torch.float32, device=DEV)
+    shift = torch.empty(B, C, dtype=torch.float32, device=DEV)
+    skws = torch.empty(32 << 20, dtype=torch.float32, device=DEV)
+    ops.set_workspace(skws)
+    try:
+        ops.groupnorm_affine(x1, gamma, beta, scale, shift, B, HW, C1, ws, x2=x2, C2=C2)
+        o_fused = torch.empty(B * HW, Cout, dtype=torch.float16, device=DEV)
+        st_f = ops.Stats(torch.zeros(ops.stats_floats(B * HW, Cout, HW), dtype=torch.float32, device=DEV))
+        ops.conv3x3_gn(x1, w, o_fused, B, H, W, C1, Cout, x2=x2, C2=C2, gn_scale=scale, gn_shift=shift, silu=True, bias=b,
+                       rowadd=radd, stats=st_f)
+        hn = torch.empty(B * HW, C, dtype=torch.float16, device=DEV)
+        ops.groupnorm(x1, gamma, beta, hn, B, HW, C1, ws, x2=x2, C2=C2)
+        o_plain = torch.empty_like(o_fused)
+        st_p = ops.Stats(torch.zeros(ops.stats_floats(B * HW, Cout, HW), dtype=torch.float32, device=DEV))
+        ops.conv3x3(hn, w, o_plain, B, H, W, C, Cout, bias=b, rowadd=radd, stats=st_p)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_workspace(None)
+    assert torch.equal(o_fused, o_plain)
+    assert st_f.P == st_p.P and torch.equal(st_f.buf[:B * st_f.P * Cout * 2], st_p.buf[:B * st_p.P * Cout * 2])
+
+
+@pytest.mark.parametrize("M,C,N,geglu,bias", [(4096, 320, 960, False, False), (1024, 640, 640, False, False), (256, 1280, 10240, True, True),
+                                             (77, 320, 2560, True, True), (3185, 320, 320, False, True)])
+def test_gemm_with_folded_layernorm(M, C, N, geglu, bias):
+    """LayerNorm -> Linear (-> GEGLU) as one contraction (lcm_gemm_ln_f16) against F.layer_norm + F.linear (+ x * gelu(gate)),
+    on rows with a large common offset (mean / std ~ 3: the cancellation the fold has to survive); every tile / variant the
+    plan table may choose gives the same bits."""
+    from sdlcm_amd.packing import pack_geglu
+    x = (rnd(M, C, seed=1).float() * 0.7 + 2.0 + rnd(M, 1, seed=8).float()).half()
+    gamma, beta = (1 + 0.2 * rnd(C, seed=2).float()).half(), rnd(C, seed=3, scale=0.2)
+    W = rnd(N, C, seed=4, scale=C ** -0.5)
+    b = rnd(N, seed=5, scale=0.3) if bias else None
+    ref = F.linear(F.layer_norm(x.float(), (C,), gamma.float(), beta.float(), 1e-5), W.float(), b.float() if bias else None)
+    Wg = W.float() * gamma.float()[None, :]
+    c = W.float() @ beta.float() + (b.float() if bias else 0.0)
+    if geglu:
+        val, gate = ref.chunk(2, dim=1)
+        ref = val * F.gelu(gate)
+        Wg, c = pack_geglu(Wg, c)
+    Wh = Wg.half()
+    g = Wh.float().sum(1)
+    outs = []
+    try:
+        for bm, bn, var in ((128, 128, -1), (64, 64, 4), (128, 64, 2), (64, 128, 0), (128, 160, 1), (64, 64, 1), (64, 128, 2), (128, 128, 0),
+                            (64, 64, 0), (128, 64, 3)):
+            if N % bn or (bn == 160 and geglu) or (bm == 128 and M < 128):
+                continue
+            ops.plan_clear()
+            ops.plan_set(0, M, N, C, 1, bm, bn, 1, var)
+            o = torch.empty(M, N // 2 if geglu else N, dtype=torch.float16, device=DEV)
+            ops.gemm_ln(x.to(DEV), Wh.to(DEV), g.to(DEV), c.to(DEV), o, epilogue=1 if geglu else 0)
+            outs.append(((bm, bn, var), o))
+        torch.cuda.synchronize()
+    finally:
+        ops.plan_reset()
+    close(outs[0][1], ref, rtol=6e-3, what="gemm with folded LayerNorm")
+    for tag, o in outs[1:]:
+        assert torch.equal(o, outs[0][1]), f"folded-LayerNorm gemm differs under plan {tag}"
+    # refresh kernel: g from the live fp16 weight, c = c_base + alpha * c_delta
+    g2 = torch.zeros(N, dtype=torch.float32, device=DEV)
+    c2 = torch.zeros(N, dtype=torch.float32, device=DEV)
+    dc = rnd(N, seed=9).float().to(DEV)
+    ops.ln_fold_refresh(Wh.to(DEV), g2, c.to(DEV), dc, 0.5, c2)
+    torch.cuda.synchronize()
+    assert (g2.cpu() - g).abs().max() < 1e-4 * max(1.0, g.abs().max().item())
+    assert torch.allclose(c2.cpu(), c + 0.5 * dc.cpu(), atol=1e-6)

@@ -228,6 +228,36 @@ def test_batched_requests_match_single_requests(state, size, steps, B):
         assert np.array_equal(one["rgb"][0], batched["rgb"][i]), f"pixels of request {i} depend on the batch"
 
 
+def test_two_lanes_in_flight_match_solo_runs(state):
+    """Two requests in flight at once on two lanes of one pipeline (own stream, scratch, graphs and split-K workspace;
+    shared weights): every result is bit-identical to the same request run alone, repeatedly, with the lanes racing."""
+    import threading
+    hip = state["hip"]
+    pe = _embeds(4, seed=33)
+    reqs = [(pe[i:i + 1], 2000 + i) for i in range(4)]
+    solo = [hip.generate(e, [s], 256, 256, 4, 1.0) for e, s in reqs]
+    assert hip.lane(1).stream is not hip.lane(0).stream and hip.lane(1).unet.w is hip.unet.w
+    assert hip.lane(1).splitk_ws.data_ptr() != hip.lane(0).splitk_ws.data_ptr()
+    got, errs = {}, []
+
+    def run(lane):
+        try:
+            for rep in range(6):
+                for k in range(4):
+                    i = (k + lane * 2) % 4
+                    out = hip.generate(reqs[i][0], [reqs[i][1]], 256, 256, 4, 1.0, lane=lane)
+                    got[(lane, rep, i)] = (out["rgb"], out["latents"])
+        except BaseException as e:      # noqa
+            errs.append(e)
+    th = [threading.Thread(target=run, args=(lane,)) for lane in (0, 1)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    assert len(got) == 48
+    for (lane, rep, i), (rgb, lat) in got.items():
+        assert np.array_equal(rgb, solo[i]["rgb"]) and np.array_equal(lat, solo[i]["latents"]), (lane, rep, i)
+
+
 def test_latents_blob_matches_oracle_pooling(state):
     from oracle import glue
     hip = state["hip"]
@@ -407,7 +437,8 @@ def test_lora_style_merge_parity_and_restore(state):
     merged = dict(usd)
     # LoCon entries: 3x3 resnet convs, the 1x1 shortcut, time_emb_proj, a stride-2 downsampler and a (phase-packed) upsampler
     conv_targets = ["down_blocks.0.resnets.1.conv1", "up_blocks.1.resnets.0.conv2", "up_blocks.2.resnets.0.conv_shortcut",
-                    "mid_block.resnets.0.time_emb_proj", "down_blocks.1.downsamplers.0.conv", "up_blocks.1.upsamplers.0.conv"]
+                    "mid_block.resnets.0.time_emb_proj", "down_blocks.1.downsamplers.0.conv", "up_blocks.1.upsamplers.0.conv",
+                    "conv_in", "conv_out"]
     for m in conv_targets:
         W = usd[m + ".weight"]
         key = "lora_unet_" + m.replace(".", "_")

@@ -7,9 +7,9 @@ export LCM_TUNE_CACHE=/tmp/tc.json
 mkdir -p gpurun_out/final
 timeout -k 10 500 python3 bench.py > gpurun_out/final/bench.json 2> gpurun_out/final/bench.err || exit 1
 echo "bench done" && cat gpurun_out/final/bench.json | cut -c1-400
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/b1 -- python3 bench.py --no-cpu-baseline --no-extra > gpurun_out/final/b1_bench.json 2> gpurun_out/final/b1.err || exit 2
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/b1 -- python3 bench.py --no-cpu-baseline --no-extra --no-roofline > gpurun_out/final/b1_bench.json 2> gpurun_out/final/b1.err || exit 2
 echo "b1 prof done"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/b8 -- python3 bench.py --batch 8 --no-cpu-baseline --no-extra > gpurun_out/final/b8_bench.json 2> gpurun_out/final/b8.err || exit 3
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/b8 -- python3 bench.py --batch 8 --no-cpu-baseline --no-extra --no-roofline > gpurun_out/final/b8_bench.json 2> gpurun_out/final/b8.err || exit 3
 echo "b8 prof done"
 for t in b1 b8; do
   f=$(find gpurun_out/final/$t -name "*kernel_stats.csv" | head -1)

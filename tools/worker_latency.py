@@ -43,7 +43,7 @@ for lvl in (6, 1):
 # ---- loaded case: N pool threads, one worker object each (as backends/worker_pool.py creates them), all
 # attached to the one resident engine; jobs queued behind a running pass coalesce into batched passes.
 import threading
-for nthreads in (1, 2, 4, 8, 16):
+for nthreads in (1, 2, 3, 4, 8, 16):
     ws = [w] + [create_hip_worker(worker_id=i) for i in range(1, nthreads)]
     per = 24
     lat = [[] for _ in ws]
@@ -54,6 +54,8 @@ for nthreads in (1, 2, 4, 8, 16):
             lat[k].append((time.perf_counter() - t0) * 1e3)
     for k in range(len(ws)):
         ws[k].run_job(Job(Req(seed=k)))
+    wu = [threading.Thread(target=lambda k=k: [ws[k].run_job(Job(Req(seed=50 + k))) for _ in range(3)]) for k in range(len(ws))]
+    [t.start() for t in wu]; [t.join() for t in wu]          # concurrent warm-up: every lane builds the plans it will use
     n0 = len(w._engine.batcher.batches) if w._engine.batcher else 0
     t0 = time.perf_counter()
     th = [threading.Thread(target=loop, args=(k,)) for k in range(len(ws))]
