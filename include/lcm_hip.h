@@ -76,9 +76,14 @@ int lcm_set_stream_workspace(void* stream, void* ptr, int64_t bytes);
  * canonical-partition heuristic: changing them changes fp32 summation order for shapes without a plan entry. */
 int lcm_set_tuning(int target_wgs, int max_splits, int min_wgs);
 /* where the canonical K partition may have more than one part: images of at most `max_rows_per_image` output rows
- * (default 1024), at most `max_parts` parts (default 4).  A deployment-wide constant: it is part of what decides the
+ * (default 4096), at most `max_parts` parts (default 8).  A deployment-wide constant: it is part of what decides the
  * fp32 summation order. */
 int lcm_set_split_policy(int max_rows_per_image, int max_parts);
+/* How a launch whose canonical partition has several parts runs: split over workgroups + reduce launch (fp32 slabs), or
+ * SEGMENTED in one workgroup (the parts accumulated separately and added in part order, in registers).  Same bits either
+ * way; 0 (default) = segmented when the unsplit launch already fills the chip (batched requests), 1 = always segmented,
+ * 2 = always split. */
+int lcm_set_seg_mode(int mode);
 
 /* Determinism.  The fp32 summation order of every output element is fixed by the K partition of its layer, and
  * that partition is a function of the PER-IMAGE problem only: (kind, rows per image, N, K[, output width]) ->
@@ -128,6 +133,10 @@ int lcm_gemm_tile_config(int M, int N, int batch);
  * (2y+py, 2x+px) only sees input rows {y-1+py, y+py} / columns {x-1+px, x+px} -- with W the phase-packed weights
  * [4 = py*2+px][Cout][2][2][Cin] (3x3 taps that land on one input pixel pre-summed): 16 instead of 36 multiply-adds
  * per output element and input channel.  Epilogue as lcm_gemm_f16.
+ * Odd targets (Upsample2D called with output_size = an odd-sized skip: F.interpolate(size=(2h-1, 2w-1), nearest),
+ * which is the 2x result minus its last row / column, then conv with ZERO padding of that cropped image): ups = 1 | 4
+ * (output height 2*Hin-1) | 8 (output width 2*Win-1), with the plain 3x3 weights -- the pre-summed phase weights of
+ * ups=2 do not hold for the border outputs, ups=2 with a crop flag is refused.
  * Preconditions: Cin % 64 == 0, Cout % 64 == 0.
  */
 int lcm_conv3x3_f16(const void* in, const void* W, const void* bias,

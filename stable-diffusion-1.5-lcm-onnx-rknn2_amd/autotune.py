@@ -54,11 +54,11 @@ def _candidates(key, meta, ws_bytes, cold=False, tune_splits=False):
         taps = 4 if meta.get("phases", 1) == 4 else 9         # phase-decomposed upsample conv: K = 4 * Cin
         units = (K // (64 * taps)) if meta["halo"] else nk    # halo conv splits over 64-channel chunks
         splits = [entry_splits]
-        if tune_splits and meta.get("splittable") and meta.get("m_img", M) == M and M <= 1024:
+        if tune_splits and meta.get("splittable") and meta.get("m_img", M) == M and M <= 4096:
             # offline, single-image shapes only, inside the library's split policy (csrc/igemm.hip lcm_split_policy:
-            # <= 1024 rows per image, <= 4 parts)
+            # <= 4096 rows per image, <= 8 parts)
             splits = [1]
-            for s in (2, 3, 4):
+            for s in (2, 3, 4, 5, 6, 8):
                 if s <= units and ntile * s <= 4096 and s * M * N * 4 <= ws_bytes and (meta["halo"] or s <= nk // 2):
                     splits.append(s)
         for s in splits:

@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256, 3) void conv_halo_kernel(HaloParams hp) {
                             if (h_pix[i] >= 0) {
 #pragma unroll
                                 for (int j = 0; j < 8; ++j) {
-                                    float f = (float)hv[i][j] * s8[j] + t8[j];
+                                    float f = __builtin_fmaf((float)hv[i][j], s8[j], t8[j]);      // as gn_apply_kernel rounds
                                     if (hp.silu) f = silu_f(f);
                                     o[j] = (half_t)f;
                                 }
@@ -239,7 +239,9 @@ __device__ __forceinline__ void halo_wait_vmcnt() {
 // (one wave per SIMD, tools/trace_conv.py): a one-tap step costs ~900 cycles for 8-16 MFMAs per wave -- barrier, LDS-DMA
 // issue and two exposed ds_read latencies -- because nothing may cross the barrier; with a row of taps per step the
 // ds_reads of tap i+1 run under the MFMAs of tap i and there is one barrier per row.
-template <int TH, int TW, int BN, int WS, int PH, int TPS>
+// SEG = 1: segmented accumulation (see igemm2_kernel): the canonical K partition (over 64-channel chunks) of a batched launch
+// is kept in registers -- finished parts are added into `tot` in part order -- instead of fp32 slabs + a reduce launch.
+template <int TH, int TW, int BN, int WS, int PH, int TPS, int SEG = 0>
 __global__ __launch_bounds__(256, 2) void conv_halo_pipe_kernel(HaloParams hp) {
     constexpr int NT = PH ? 4 : 9;
     constexpr int G = NT / TPS;            // K-steps per 64-channel chunk
@@ -338,6 +340,15 @@ __global__ __launch_bounds__(256, 2) void conv_halo_pipe_kernel(HaloParams hp) {
     for (int s = 0; s < WS - 1; ++s)
         if (s < T) issue_w(s, s);
 
+    f4 tot[SEG ? TN : 1][SEG ? TM : 1];
+    int part = 0, kstep = 0, plen = T;     // SEG: K-steps of the current part (parts = ranges of 64-channel chunks)
+    if constexpr (SEG) {
+#pragma unroll
+        for (int a = 0; a < TN; ++a)
+#pragma unroll
+            for (int b = 0; b < TM; ++b) tot[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
+        plen = (int)((long long)nchunks / p.seg_parts) * G;
+    }
     int wb = 0;
     constexpr int LPS = RW * TPS;          // LDS-DMA instructions per thread per K-step
     for (int t = 0; t < T; ++t) {
@@ -378,43 +389,57 @@ __global__ __launch_bounds__(256, 2) void conv_halo_pipe_kernel(HaloParams hp) {
                         acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[a], xf[b], acc[a][b], 0, 0, 0);
             }
         } else {
-            // a row of taps per step, software-pipelined over the taps: the fragments of tap i+1 are fetched from LDS
-            // while the MFMAs of tap i run (one wave per SIMD has nobody else to hide the ds_read latency behind)
-            h8 xf[2][2][TM], wf[2][2][TN];
-            auto load_frags = [&](int tp, int buf) {
+            // a row of taps per step, software-pipelined over HALF taps (32 of the 64 channels of a tap): the fragments of
+            // half-step h+1 are fetched from LDS while the MFMAs of half-step h run (one wave per SIMD has nobody else to hide
+            // the ds_read latency behind).  Half a tap, not a whole one: lgkmcnt is a 4-bit counter, and with two whole taps
+            // of fragment reads in flight (24 for the 128x64 tile) the compiler can only wait for ALL of them
+            // (s_waitcnt lgkmcnt(0)) before the first MFMA -- which serialises exactly the two phases this is meant to overlap.
+            h8 xf[2][TM], wf[2][TN];
+            auto load_half = [&](int h, int buf) {
+                const int tp = h >> 1, kk = h & 1;
                 const int tapoff = (tg + (PH ? py : 0)) * HWD + tp + (PH ? px : 0);
                 const char* wsr = wsm0 + wb * SBYTES + tp * WBYTES + (wn * (BN / 2)) * 128;
+                const int c = kk * 4 + fq;
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    const int c = kk * 4 + fq;
+                for (int b = 0; b < TM; ++b) {
+                    const int r = rb0 + b * RB_STEP + tapoff;
+                    xf[buf][b] = *reinterpret_cast<const h8*>(xs + r * 128 + ((c ^ (r & 7)) << 4));
+                }
 #pragma unroll
-                    for (int b = 0; b < TM; ++b) {
-                        const int r = rb0 + b * RB_STEP + tapoff;
-                        xf[buf][kk][b] = *reinterpret_cast<const h8*>(xs + r * 128 + ((c ^ (r & 7)) << 4));
-                    }
-#pragma unroll
-                    for (int a = 0; a < TN; ++a) {
-                        const int r = a * 16 + frow;
-                        wf[buf][kk][a] = *reinterpret_cast<const h8*>(wsr + r * 128 + ((c ^ (r & 7)) << 4));
-                    }
+                for (int a = 0; a < TN; ++a) {
+                    const int r = a * 16 + frow;
+                    wf[buf][a] = *reinterpret_cast<const h8*>(wsr + r * 128 + ((c ^ (r & 7)) << 4));
                 }
             };
-            load_frags(0, 0);
+            load_half(0, 0);
 #pragma unroll
-            for (int tp = 0; tp < TPS; ++tp) {
-                if (tp + 1 < TPS) load_frags(tp + 1, (tp + 1) & 1);
+            for (int h = 0; h < 2 * TPS; ++h) {
+                if (h + 1 < 2 * TPS) load_half(h + 1, (h + 1) & 1);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk)
+                for (int a = 0; a < TN; ++a)
 #pragma unroll
-                    for (int a = 0; a < TN; ++a)
-#pragma unroll
-                        for (int b = 0; b < TM; ++b)
-                            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[tp & 1][kk][a], xf[tp & 1][kk][b], acc[a][b], 0, 0, 0);
+                    for (int b = 0; b < TM; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[h & 1][a], xf[h & 1][b], acc[a][b], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
         wb = (wb + 1 == WS) ? 0 : wb + 1;
+        if constexpr (SEG) {
+            if (++kstep == plen) {         // a part of the canonical K partition is complete: fold it in, in part order
+                kstep = 0;
+#pragma unroll
+                for (int a = 0; a < TN; ++a)
+#pragma unroll
+                    for (int b = 0; b < TM; ++b) {
+                        tot[a][b][0] += acc[a][b][0]; tot[a][b][1] += acc[a][b][1];
+                        tot[a][b][2] += acc[a][b][2]; tot[a][b][3] += acc[a][b][3];
+                        acc[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
+                    }
+                ++part;
+                plen = ((int)((long long)(part + 1) * nchunks / p.seg_parts) - (int)((long long)part * nchunks / p.seg_parts)) * G;
+            }
+        }
     }
 
     int m_of[TM];
@@ -426,13 +451,12 @@ __global__ __launch_bounds__(256, 2) void conv_halo_pipe_kernel(HaloParams hp) {
     }
     int slab_of[BM / 64];
     halo_slabs<TH, TW, PH>(slab_of, wm, bimg, y0, x0, IH, IW, phase);
-    igemm_epilogue<BM, BN>(p, acc, m_of, n_base + wn * (BN / 2), fq, 0, slab_of);
+    if constexpr (SEG) igemm_epilogue<BM, BN>(p, tot, m_of, n_base + wn * (BN / 2), fq, 0, slab_of);
+    else igemm_epilogue<BM, BN>(p, acc, m_of, n_base + wn * (BN / 2), fq, 0, slab_of);
 }
 
 // split-K combine kernel lives in igemm.hip
 extern void lcm_launch_splitk_reduce(IgemmParams& p, hipStream_t s);
-extern int lcm_reduce_rows(int hw);
-extern int lcm_reduce_slabs(int hw);
 extern float* lcm_splitk_workspace(long long* bytes, hipStream_t s);
 extern void lcm_tuning(int* target_wgs, int* max_splits, int* min_wgs);
 extern int lcm_split_policy(int m_img, int sp);
@@ -449,6 +473,26 @@ static void launch_halo(HaloParams& hp, hipStream_t s, int force) {     // force
     hp.tiles_x = ((PH ? hp.g.Win : hp.W) + TW - 1) / TW;
     hp.g.ntiles = hp.g.N / BN;
     dim3 grid(hp.g.mtiles * hp.g.ntiles, hp.g.splits, 1);
+    if constexpr (!XFORM) if (hp.g.seg_parts > 1) {     // segmented accumulation: the pipelined kernel (2 workgroups per CU: room for `tot`)
+        // (a kernel row of taps per step double-buffers its fragments in registers: with the second accumulator set that only
+        // fits the 64-wide tile; wider tiles take one tap per step)
+        constexpr int TPS = (BN <= 64) ? (PH ? 2 : 3) : 1;
+        constexpr int WS = 3;
+        constexpr int smem = 2 * HROWS_PAD * 128 + WS * TPS * BN * 128;
+        static_assert(smem <= 160 * 1024, "halo ring exceeds LDS");
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_pipe_kernel<TH, TW, BN, WS, PH, TPS, 1>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            attr_set = true;
+        }
+        char nm[80];
+        snprintf(nm, sizeof(nm), "conv_halo_pipe_kernel<%d, %d, %d, %d, %d, %d, 1>", TH, TW, BN, WS, PH, TPS);
+        lcm_prof_start(nm, s);
+        hipLaunchKernelGGL((conv_halo_pipe_kernel<TH, TW, BN, WS, PH, TPS, 1>), grid, dim3(256), smem, s, hp);
+        lcm_prof_stop(s);
+        return;
+    }
     if constexpr (!XFORM && BN <= 128) if (force == 3) {
         // one kernel row of taps per K-step (plan variant 3): batch-1 launches, one workgroup per CU
         constexpr int TPS = PH ? 2 : 3;
@@ -550,12 +594,6 @@ int lcm_conv_halo_launch(HaloParams& hp, int B, hipStream_t s, int* slabs_per_im
     p.img_rows = m_img;
     // the K partition: a function of the per-image problem only
     const int splits = p.ws ? lcm_canonical_splits_halo(m_img, p.N, p.K, IH, IW, hp.W, ph ? 1 : 0, hp.gn_scale ? 1 : 0) : 1;
-    if (splits > 1 && (long long)splits * p.M * p.N * 4 > ws_bytes) {
-        lcm_set_error("split-K workspace too small: %d x %d x %d fp32 slabs need %lld MB, have %lld MB "
-                      "(lcm_set_workspace / LCM_SPLITK_WS_MB)", splits, p.M, p.N,
-                      ((long long)splits * p.M * p.N * 4 + (1 << 20) - 1) >> 20, ws_bytes >> 20);
-        return LCM_EINVAL;
-    }
     // tile / variant: launch parameters (plan entry of the total shape, else the occupancy heuristic)
     HaloPick hk = halo_pick(B, IH, IW, PHM, TW, p.M, p.N, nchunks, splits);
     int bm = hk.bm, bn = hk.bn, force = 0;
@@ -571,13 +609,23 @@ int lcm_conv_halo_launch(HaloParams& hp, int B, hipStream_t s, int* slabs_per_im
     const int th = bm / TW;
     p.mtiles = B * ((IH + th - 1) / th) * ((IW + TW - 1) / TW) * PHM;
     p.splits = splits;
-    if (p.stats) {   // fused GroupNorm statistics of the output
+    p.seg_parts = 1;
+    if (splits > 1 && !hp.gn_scale) {   // a batched launch that fills the chip unsplit keeps the canonical partition in registers
+        extern int g_seg_mode;
+        int tgt, mxs, min_wgs;
+        lcm_tuning(&tgt, &mxs, &min_wgs);
+        if (g_seg_mode == 1 || (g_seg_mode == 0 && (long long)p.mtiles * (p.N / bn) >= min_wgs)) { p.seg_parts = splits; p.splits = 1; }
+    }
+    if (p.splits > 1 && (long long)p.splits * p.M * p.N * 4 > ws_bytes) {
+        lcm_set_error("split-K workspace too small: %d x %d x %d fp32 slabs need %lld MB, have %lld MB "
+                      "(lcm_set_workspace / LCM_SPLITK_WS_MB)", p.splits, p.M, p.N,
+                      ((long long)p.splits * p.M * p.N * 4 + (1 << 20) - 1) >> 20, ws_bytes >> 20);
+        return LCM_EINVAL;
+    }
+    p.rg_kind = TW == 16 ? 1 : 2; p.rg_ph = ph ? 1 : 0; p.rg_IH = IH; p.rg_IW = IW; p.rg_OH = hp.H; p.rg_OW = hp.W;
+    if (p.stats) {   // fused GroupNorm statistics of the output: canonical 32-pixel slabs (halo_slabs / splitk_reduce_kernel)
         if (p.N > 2048) p.stats = nullptr;
-        else if (splits > 1) {
-            if (slabs_per_image) *slabs_per_image = lcm_reduce_slabs(hp.H * hp.W);
-        } else if (slabs_per_image) {
-            *slabs_per_image = halo_slabs_per_image(IH, IW, TW, ph);      // canonical 32-pixel slabs (halo_slabs)
-        }
+        else if (slabs_per_image) *slabs_per_image = halo_slabs_per_image(IH, IW, TW, ph);
     }
     const bool xf = hp.gn_scale != nullptr;
     if (ph && xf) return 1;
@@ -590,6 +638,6 @@ int lcm_conv_halo_launch(HaloParams& hp, int B, hipStream_t s, int* slabs_per_im
     HALO_CASE(8, 16, 128) HALO_CASE(8, 16, 64) HALO_CASE(4, 16, 128) HALO_CASE(4, 16, 64)
     HALO_CASE(8, 8, 128) HALO_CASE(8, 8, 64) HALO_CASE(8, 16, 160) HALO_CASE(4, 16, 160) HALO_CASE(8, 8, 160) { return 1; }
 #undef HALO_CASE
-    if (splits > 1) lcm_launch_splitk_reduce(p, s);
+    if (p.splits > 1) lcm_launch_splitk_reduce(p, s);
     return 0;
 }

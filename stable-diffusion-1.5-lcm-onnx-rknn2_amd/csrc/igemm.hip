@@ -191,8 +191,12 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int MODE, int S, int LN = 0>
+template <int BM, int BN, int MODE, int S, int LN = 0, int SEG = 0>
 __global__ __launch_bounds__(256, S == 1 ? (BM + BN < 256 ? 4 : 3) : 2) void igemm2_kernel(IgemmParams p) {
+    // SEG = 1: segmented accumulation.  The launch's canonical K partition has p.seg_parts parts but this (batched) launch
+    // fills the chip without splitting: one workgroup walks all of K, keeps the running part in `acc` and adds the finished
+    // parts into `tot` in part order -- the additions the split-K reduce makes, in registers, with no fp32 slabs in HBM.
+    static_assert(!SEG || (S >= 2 && !LN), "segmented accumulation: ring variants of the plain kernel");
     constexpr int RA = BM / 32, RW = BN / 32;
     constexpr int TM = BM / 32, TN = BN / 32;
     constexpr int XBYTES = BM * 128, WBYTES = BN * 128, BUF = XBYTES + WBYTES;
@@ -309,6 +313,15 @@ __global__ __launch_bounds__(256, S == 1 ? (BM + BN < 256 ? 4 : 3) : 2) void ige
     for (int s = 0; s < S - 1; ++s)
         if (s < T) issue_tile(s, s);
 
+    f4 tot[SEG ? TN : 1][SEG ? TM : 1];
+    int part = 0, nkp = nkr;               // SEG: k-tiles of the current part
+    if constexpr (SEG) {
+#pragma unroll
+        for (int a = 0; a < TN; ++a)
+#pragma unroll
+            for (int b = 0; b < TM; ++b) tot[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
+        nkp = (int)((long long)nk_all / p.seg_parts);          // part 0 = k-tiles [0, nk_all / parts)
+    }
     int buf = 0, kstep = 0, ni_cur = 0;
     for (int t = 0; t < T; ++t) {
         // tile t must have landed; up to min(S-2, tiles issued after t) newer tiles may stay in flight
@@ -355,6 +368,22 @@ __global__ __launch_bounds__(256, S == 1 ? (BM + BN < 256 ? 4 : 3) : 2) void ige
                     acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[a], xf[b], acc[a][b], 0, 0, 0);
         }
         buf = (buf + 1 == S) ? 0 : buf + 1;
+        if constexpr (SEG) {
+            if (++kstep == nkp) {          // a part of the canonical K partition is complete: fold it in, in part order
+                kstep = 0;
+#pragma unroll
+                for (int a = 0; a < TN; ++a)
+#pragma unroll
+                    for (int b = 0; b < TM; ++b) {
+                        tot[a][b][0] += acc[a][b][0]; tot[a][b][1] += acc[a][b][1];
+                        tot[a][b][2] += acc[a][b][2]; tot[a][b][3] += acc[a][b][3];
+                        acc[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
+                    }
+                ++part;
+                nkp = (int)((long long)(part + 1) * nk_all / p.seg_parts) - (int)((long long)part * nk_all / p.seg_parts);
+            }
+            continue;
+        }
         if (++kstep == nkr) {          // this n-tile is complete: epilogue while the next tile's loads are in flight
             kstep = 0;
             int m_of[TM];
@@ -382,70 +411,92 @@ __global__ __launch_bounds__(256, S == 1 ? (BM + BN < 256 ? 4 : 3) : 2) void ige
                 for (int b = 0; b < TM; ++b) acc[a][b] = (f4){0.f, 0.f, 0.f, 0.f};
         }
     }
+    if constexpr (SEG) {
+        int m_of[TM];
+#pragma unroll
+        for (int b = 0; b < TM; ++b) {
+            const int m = m_base + wm * (BM / 2) + b * 16 + frow;
+            m_of[b] = m < p.M ? m : -1;
+        }
+        int slab_of[BM / 64];
+#pragma unroll
+        for (int bp = 0; bp < BM / 64; ++bp) {
+            const int r = m_base + wm * (BM / 2) + bp * 32;
+            slab_of[bp] = r < p.M ? (r >> 5) : -1;
+        }
+        igemm_epilogue<BM, BN>(p, tot, m_of, nt0 * BN + wn * (BN / 2), fq, z, slab_of);
+    }
 }
 
-// Split-K combine: fixed-order sum of the fp32 slabs (bit-reproducible) + the epilogue of the main kernel, and
-// optionally the fused GroupNorm statistics of the result.  A workgroup owns p.reduce_rows consecutive rows; a thread
-// owns one 4-channel group and walks rows, so per-channel sums need only a fixed-order fold over the row lanes.
-#define RED_THREADS 1024
-__global__ __launch_bounds__(RED_THREADS) void splitk_reduce_kernel(IgemmParams p) {
-    __shared__ float red[RED_THREADS * 4 * 2];
-    const int n4 = p.N >> 2, tid = threadIdx.x;
-    // workgroup = one slab of one image: rows [s * reduce_rows, (s+1) * reduce_rows) of image b, the last slab of an image
-    // may be short (image sizes that are no multiple of the slab height); slabs never straddle images
-    const int hw = p.img_rows > 0 ? p.img_rows : p.M;
-    const int spi = (hw + p.reduce_rows - 1) / p.reduce_rows;             // slabs per image
-    const int bimg = blockIdx.x / spi, sl = blockIdx.x - bimg * spi;
-    const int r0 = bimg * hw + sl * p.reduce_rows, r1 = min(bimg * hw + hw, r0 + p.reduce_rows);
-    const long long slab = (long long)p.M * p.N;
-    const bool small = n4 <= RED_THREADS;
-    const int nrl = small ? RED_THREADS / n4 : 1;        // row lanes: threads that share a channel group
-    const int rl = small ? tid / n4 : 0;
-    const bool do_stats = p.stats != nullptr;
-    for (int cg = small ? tid - rl * n4 : tid; cg < n4; cg += RED_THREADS) {
-        const int n = cg * 4;
-        float ss[4] = {0.f, 0.f, 0.f, 0.f}, qq[4] = {0.f, 0.f, 0.f, 0.f};
-        if (rl < nrl) {
-            f4 bias4 = {0.f, 0.f, 0.f, 0.f};
-            if (p.bias) { h4 t = *reinterpret_cast<const h4*>(p.bias + n); bias4 = (f4){(float)t[0], (float)t[1], (float)t[2], (float)t[3]}; }
-            for (int m = r0 + rl; m < r1; m += nrl) {
-                const float* src = p.ws + (long long)m * p.N + n;
-                f4 v = *reinterpret_cast<const f4*>(src);
-                for (int s = 1; s < p.splits; ++s) {
-                    f4 t = *reinterpret_cast<const f4*>(src + s * slab);
-                    v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
-                }
-                v[0] += bias4[0]; v[1] += bias4[1]; v[2] += bias4[2]; v[3] += bias4[3];
-                if (p.rowadd) { h4 t = *reinterpret_cast<const h4*>(p.rowadd + (long long)(m / p.rows_per_batch) * p.ld_rowadd + n);
-                    v[0] += (float)t[0]; v[1] += (float)t[1]; v[2] += (float)t[2]; v[3] += (float)t[3]; }
-                v[0] *= p.out_scale; v[1] *= p.out_scale; v[2] *= p.out_scale; v[3] *= p.out_scale;
-                if (p.res) { h4 t = *reinterpret_cast<const h4*>(p.res + (long long)m * p.ldr + n);
-                    v[0] += (float)t[0]; v[1] += (float)t[1]; v[2] += (float)t[2]; v[3] += (float)t[3]; }
-                h4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-                *reinterpret_cast<h4*>(p.out + (long long)m * p.ldo + n) = o;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { const float f = (float)o[j]; ss[j] += f; qq[j] += f * f; }
-            }
-        }
-        if (do_stats) {
-            if (!small) {       // one thread owns the channel group for the whole slab
-                float* dst = p.stats + ((long long)blockIdx.x * p.N + n) * 2;
-                *reinterpret_cast<f4*>(dst) = (f4){ss[0], qq[0], ss[1], qq[1]};
-                *reinterpret_cast<f4*>(dst + 4) = (f4){ss[2], qq[2], ss[3], qq[3]};
-            } else if (rl < nrl) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { red[((rl * p.N) + n + j) * 2] = ss[j]; red[((rl * p.N) + n + j) * 2 + 1] = qq[j]; }
-            }
-        }
-        if (small) break;
+// Split-K combine: fixed-order sum of the fp32 slabs (bit-reproducible) + the epilogue of the main kernel, and optionally
+// the fused GroupNorm statistics of the result -- written per CANONICAL 32-pixel slab, with the pixels of a slab visited
+// and folded exactly as igemm_epilogue does it (two 16-pixel fragments per lane-row, then the 16-lane butterfly), so a
+// layer's statistics are the same bits whether it ran split (this kernel), segmented in one workgroup, or unsplit.
+// One wave = one slab x 16 channels: lane (l = lane & 15, fq = lane >> 4) owns pixel l of both fragments, channels 4fq..4fq+3.
+__device__ __forceinline__ int reduce_pixel(const IgemmParams& p, int slab, int b, int l) {
+    if (p.rg_kind == 0) {
+        const int m = slab * 32 + b * 16 + l;
+        return m < p.M ? m : -1;
     }
-    if (do_stats && small) {
-        __syncthreads();
-        for (int c = tid; c < p.N; c += RED_THREADS) {
-            float s = 0.f, q = 0.f;
-            for (int r = 0; r < nrl; ++r) { s += red[(r * p.N + c) * 2]; q += red[(r * p.N + c) * 2 + 1]; }
-            float* dst = p.stats + ((long long)blockIdx.x * p.N + c) * 2;
-            dst[0] = s; dst[1] = q;
+    const int TW = p.rg_kind == 1 ? 16 : 8, RS = 32 / TW;
+    const int sx = (p.rg_IW + TW - 1) / TW, sy = (p.rg_IH + RS - 1) / RS;
+    int phase = 0;
+    if (p.rg_ph) { phase = slab & 3; slab >>= 2; }
+    const int bimg = slab / (sy * sx), r = slab - bimg * (sy * sx);
+    const int syi = r / sx, sxi = r - syi * sx;
+    const int q = b * 16 + l;                          // pixel of the slab, row-major over its RS x TW patch
+    const int y = syi * RS + q / TW, x = sxi * TW + q % TW;
+    if (y >= p.rg_IH || x >= p.rg_IW) return -1;
+    if (p.rg_ph) return (bimg * p.rg_OH + 2 * y + (phase >> 1)) * p.rg_OW + 2 * x + (phase & 1);
+    return (bimg * p.rg_OH + y) * p.rg_OW + x;
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(IgemmParams p, int total_slabs) {
+#pragma clang fp contract(off)
+    const int lane = threadIdx.x & 63, ncg = p.N >> 4;
+    const long long wv = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int slab = (int)(wv / ncg), cg = (int)(wv - (long long)slab * ncg);
+    if (slab >= total_slabs) return;
+    const int l = lane & 15, fq = lane >> 4;
+    const int n = cg * 16 + fq * 4;
+    const long long slab_stride = (long long)p.M * p.N;
+    f4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) { h4 t = *reinterpret_cast<const h4*>(p.bias + n); bias4 = (f4){(float)t[0], (float)t[1], (float)t[2], (float)t[3]}; }
+    float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int m = reduce_pixel(p, slab, b, l);
+        if (m < 0) continue;
+        const float* src = p.ws + (long long)m * p.N + n;
+        f4 v = *reinterpret_cast<const f4*>(src);
+        for (int s = 1; s < p.splits; ++s) {
+            f4 t = *reinterpret_cast<const f4*>(src + s * slab_stride);
+            v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
+        }
+        v[0] += bias4[0]; v[1] += bias4[1]; v[2] += bias4[2]; v[3] += bias4[3];
+        if (p.rowadd) { h4 t = *reinterpret_cast<const h4*>(p.rowadd + (long long)(m / p.rows_per_batch) * p.ld_rowadd + n);
+            v[0] += (float)t[0]; v[1] += (float)t[1]; v[2] += (float)t[2]; v[3] += (float)t[3]; }
+        v[0] *= p.out_scale; v[1] *= p.out_scale; v[2] *= p.out_scale; v[3] *= p.out_scale;
+        if (p.res) { h4 t = *reinterpret_cast<const h4*>(p.res + (long long)m * p.ldr + n);
+            v[0] += (float)t[0]; v[1] += (float)t[1]; v[2] += (float)t[2]; v[3] += (float)t[3]; }
+        h4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+        *reinterpret_cast<h4*>(p.out + (long long)m * p.ldo + n) = o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float f = (float)o[j]; ssum[j] += f; ssq[j] += f * f; }
+    }
+    if (p.stats) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+                ssum[j] += __shfl_xor(ssum[j], o, 64);
+                ssq[j] += __shfl_xor(ssq[j], o, 64);
+            }
+        }
+        if (l == 0) {
+            float* dst = p.stats + ((long long)slab * p.N + n) * 2;
+            *reinterpret_cast<f4*>(dst) = (f4){ssum[0], ssq[0], ssum[1], ssq[1]};
+            *reinterpret_cast<f4*>(dst + 4) = (f4){ssum[2], ssq[2], ssum[3], ssq[3]};
         }
     }
 }
@@ -487,21 +538,18 @@ float* lcm_splitk_workspace(long long* bytes, hipStream_t s) {
     *bytes = g_ws[dev] ? g_ws_bytes[dev] : 0;
     return g_ws[dev];
 }
-// rows per reduce workgroup: a power of two <= 32 chosen from `hw` = output rows PER IMAGE only (the slab structure --
-// hence the order in which the fused statistics are summed -- depends on the image shape, never on how many images share
-// the launch) so that an image has >= ~128 slabs where it can; ceil(hw / rows) slabs per image, the last one may be short
-int lcm_reduce_rows(int hw) {
-    int rs = 32;
-    while (rs > 1 && (hw + rs - 1) / rs < 128) rs >>= 1;
-    return rs;
+// number of canonical slabs of a launch's output (all images)
+int lcm_total_slabs(const IgemmParams& p) {
+    if (p.rg_kind == 0) return (p.M + 31) / 32;
+    const int TW = p.rg_kind == 1 ? 16 : 8, RS = 32 / TW;
+    const int per_img = ((p.rg_IH + RS - 1) / RS) * ((p.rg_IW + TW - 1) / TW) * (p.rg_ph ? 4 : 1);
+    return (p.M / (p.rg_OH * p.rg_OW)) * per_img;
 }
-int lcm_reduce_slabs(int hw) { const int rs = lcm_reduce_rows(hw); return (hw + rs - 1) / rs; }
 
 void lcm_launch_splitk_reduce(IgemmParams& p, hipStream_t s) {
-    const int hw = p.img_rows > 0 && p.M % p.img_rows == 0 ? p.img_rows : p.M;
-    p.img_rows = hw;
-    p.reduce_rows = lcm_reduce_rows(hw);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((p.M / hw) * lcm_reduce_slabs(hw))), dim3(RED_THREADS), 0, s, p);
+    const int total = lcm_total_slabs(p);
+    const long long waves = (long long)total * (p.N >> 4);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, p, total);
 }
 
 // ---- per-shape launch plans (filled by the host-side autotuner; heuristics below are the fallback) ----
@@ -546,7 +594,9 @@ bool lcm_plan_get(int kind, int M, int N, int K, int aux, int* bm, int* bn, int*
 // entry of the TOTAL shape (tuned freely) or the occupancy heuristic.
 struct TilePick { int bm, bn, splits; };
 static int g_target_wgs = 384, g_max_splits = 16, g_min_wgs = 256;
-static int g_split_max_rows = 1024, g_split_cap = 4;
+static int g_split_max_rows = 4096, g_split_cap = 8;
+int g_seg_mode = 0;            // 0: segmented accumulation when the unsplit launch has >= min_wgs tiles; 1: whenever the partition
+                               // has parts; 2: never (always split + reduce) -- all three give the same bits
 static int g_variant = -1;     // -1: auto (1 stage when >= 4 workgroups per CU are available, else 2); 0: register-staged
                                // double buffer (v1); 1/2/3/4: LDS-DMA pipeline with that many stages
 
@@ -572,6 +622,12 @@ extern "C" int lcm_set_tuning(int target_wgs, int max_splits, int min_wgs) {
     if (target_wgs > 0) g_target_wgs = target_wgs;
     if (max_splits > 0) g_max_splits = max_splits;
     if (min_wgs > 0) g_min_wgs = min_wgs;
+    return LCM_OK;
+}
+
+extern "C" int lcm_set_seg_mode(int mode) {
+    if (mode < 0 || mode > 2) { lcm_set_error("seg_mode: %d", mode); return LCM_EINVAL; }
+    g_seg_mode = mode;
     return LCM_OK;
 }
 
@@ -609,10 +665,9 @@ static TilePick pick_tile(int M, int N, int K, int batch, int fixed_splits) {
     return best;
 }
 
-// The partition is paid for at every batch size (a batch of 8 splits every image the way a lone image is split, and the
-// fp32 slabs then cost HBM traffic the batched launch would not otherwise need), so it is kept to where a lone image
-// cannot fill the chip any other way: at most 1024 output rows per image (the 32x32 latent level and below) and at most
-// 4 parts (at batch 1 the measured difference between 4 and 10 parts is within noise: profiles/r01_chain_latency_conv.txt).
+// Where the canonical partition may have parts: images of at most 4096 output rows (the 64x64 latent level and below), at
+// most 8 parts.  A batched launch pays nothing for it (segmented accumulation keeps the parts in registers); what the bound
+// limits is the fp32 slab traffic of the launches in between (2-4 images, too few tiles to go unsplit).
 int lcm_split_policy(int m_img, int sp) {
     if (m_img > g_split_max_rows) return 1;
     if (sp > g_split_cap) sp = g_split_cap;
@@ -646,19 +701,19 @@ extern "C" int lcm_gemm_tile_config(int M, int N, int batch) {
     return t.bm * 1000 + t.bn;
 }
 
-template <int BM, int BN, int MODE, int S, int LN = 0>
+template <int BM, int BN, int MODE, int S, int LN = 0, int SEG = 0>
 static int launch_v2(IgemmParams& p, dim3 grid, hipStream_t s) {
     constexpr int smem = S * (BM + BN) * 128 + (LN ? 2 * BN * 4 : 0);       // LN: + this n-tile's ln_g | ln_c
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<BM, BN, MODE, S, LN>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<BM, BN, MODE, S, LN, SEG>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_set = true;
     }
     char nm[64];
-    snprintf(nm, sizeof(nm), "igemm2_kernel<%d, %d, %d, %d, %d>%s", BM, BN, MODE, S, LN, p.splits > 1 ? " +splitk" : "");
+    snprintf(nm, sizeof(nm), "igemm2_kernel<%d, %d, %d, %d, %d, %d>%s", BM, BN, MODE, S, LN, SEG, p.splits > 1 ? " +splitk" : "");
     lcm_prof_start(nm, s);
-    hipLaunchKernelGGL((igemm2_kernel<BM, BN, MODE, S, LN>), grid, dim3(256), smem, s, p);
+    hipLaunchKernelGGL((igemm2_kernel<BM, BN, MODE, S, LN, SEG>), grid, dim3(256), smem, s, p);
     lcm_prof_stop(s);
     return 0;
 }
@@ -693,6 +748,15 @@ static int launch_cfg(IgemmParams& p, int batch, int splits, int plan_variant, h
     }
     if (p.n_iters > 1 && variant == 1) variant = 2;
     if (variant == 4 && BM + BN > 192) variant = 3;      // 4 x 32 KiB stages only for the small tiles
+    if constexpr (!LN) if (p.seg_parts > 1) {             // segmented accumulation: ring variants only
+        if (variant < 2 || variant > 4) variant = (BM + BN <= 128) ? 4 : 2;
+        if (variant == 2) launch_v2<BM, BN, MODE, 2, 0, 1>(p, grid, s);
+        else if (variant == 3) launch_v2<BM, BN, MODE, 3, 0, 1>(p, grid, s);
+        else if constexpr (BM + BN <= 192) launch_v2<BM, BN, MODE, 4, 0, 1>(p, grid, s);
+        else launch_v2<BM, BN, MODE, 3, 0, 1>(p, grid, s);
+        LCM_CHECK_LAUNCH("igemm");
+        return LCM_OK;
+    }
     if (variant == 0) {
         const int smem = 2 * (BM + BN) * 128;
         static bool attr_set = false;
@@ -738,12 +802,6 @@ static int launch_igemm(IgemmParams& p, int batch, hipStream_t s, int img_rows, 
     int splits = 1;
     if (allow_split && p.ws && p.epi == 0 && batch == 1) {      // no workspace registered: the library never splits
         splits = canonical_splits_gemm(MODE, img_rows, p.N, p.K);
-        if (splits > 1 && (long long)splits * p.M * p.N * 4 > wsb) {
-            lcm_set_error("split-K workspace too small: %d x %d x %d fp32 slabs need %lld MB, have %lld MB "
-                          "(lcm_set_workspace / LCM_SPLITK_WS_MB)", splits, p.M, p.N,
-                          ((long long)splits * p.M * p.N * 4 + (1 << 20) - 1) >> 20, wsb >> 20);
-            return LCM_EINVAL;
-        }
     }
     TilePick t = pick_tile(p.M, p.N, p.K, batch, splits);
     int variant = -1, pbm, pbn, psp, pv;
@@ -756,14 +814,22 @@ static int launch_igemm(IgemmParams& p, int batch, hipStream_t s, int img_rows, 
     }
     if (slabs_per_image) *slabs_per_image = 0;
     p.stats = want_stats ? p.stats : nullptr;
+    p.rg_kind = 0;
     if (p.stats) {
         const bool ok = p.epi == 0 && batch == 1 && p.N <= 2048 && img_rows % 32 == 0;
-        if (p.epi == 0 && batch == 1 && p.N <= 2048 && splits > 1) {      // reduce slabs: any image size
-            if (slabs_per_image) *slabs_per_image = lcm_reduce_slabs(img_rows);
-        } else if (ok) {
-            if (slabs_per_image) *slabs_per_image = img_rows / 32;       // canonical 32-row slabs (igemm_epilogue)
-        }
-        if (!ok && !(p.epi == 0 && batch == 1 && p.N <= 2048 && splits > 1)) p.stats = nullptr;
+        if (ok && slabs_per_image) *slabs_per_image = img_rows / 32;       // canonical 32-row slabs (igemm_epilogue / reduce)
+        if (!ok) p.stats = nullptr;
+    }
+    p.seg_parts = 1;
+    if (splits > 1) {    // a batched launch that fills the chip unsplit keeps the canonical partition in registers instead
+        const long long tiles = (long long)((p.M + t.bm - 1) / t.bm) * (p.N / t.bn) * batch;
+        if (g_seg_mode == 1 || (g_seg_mode == 0 && tiles >= g_min_wgs)) { p.seg_parts = splits; splits = 1; }
+    }
+    if (splits > 1 && (long long)splits * p.M * p.N * 4 > wsb) {
+        lcm_set_error("split-K workspace too small: %d x %d x %d fp32 slabs need %lld MB, have %lld MB "
+                      "(lcm_set_workspace / LCM_SPLITK_WS_MB)", splits, p.M, p.N,
+                      ((long long)splits * p.M * p.N * 4 + (1 << 20) - 1) >> 20, wsb >> 20);
+        return LCM_EINVAL;
     }
     const int code = t.bm * 1000 + t.bn;
     if constexpr (MODE == 0) if (p.ln_g) {     // LayerNorm-folded GEMM: its own instantiations (compile-time switch in the K loop)

@@ -24,7 +24,14 @@ struct IgemmParams {
     float* ws;           // fp32 [splits][M][N]
     float* stats;        // optional fused GroupNorm statistics of the OUTPUT: [slab][N][2] = per-channel (sum, sum of
                          // squares) of the fp16-rounded values each half-tile (or reduce slab) stores; null = off
-    int reduce_rows;     // rows per workgroup of splitk_reduce_kernel
+    int reduce_rows;     // (unused)
+    // geometry of the canonical 32-pixel statistics slabs of the OUTPUT (splitk_reduce_kernel walks them; it must visit
+    // the pixels of a slab in exactly the order a tile epilogue does): rg_kind 0 = 32 consecutive rows, 1 = 2x16 pixel
+    // patches, 2 = 4x8 patches of an rg_IH x rg_IW image (the input image when rg_ph, four phase slabs per patch);
+    // output image rg_OH x rg_OW
+    int rg_kind, rg_ph, rg_IH, rg_IW, rg_OH, rg_OW;
+    int seg_parts;       // > 1: ONE workgroup walks all K, accumulating the canonical parts separately and adding them in
+                         // part order (bit-identical to the split launch + reduce, no fp32 slabs): batched launches
     int img_rows;        // output rows per image (GEMM kinds; 0 = one image)
     // LayerNorm folded into the GEMM that consumes it (lcm_gemm_ln_f16): W holds gamma (*) W, the kernel accumulates the
     // row sums of A while it walks K and the epilogue applies  y = rstd * (acc - mean * ln_g[n]) + ln_c[n]
@@ -62,7 +69,7 @@ __device__ __forceinline__ void ln_finish(float (&s)[TM], float (&q)[TM], int K,
         ss += __shfl_xor(ss, 32, 64); qq += __shfl_xor(qq, 32, 64);
         const float mean = ss * inv;
         s[b] = mean;
-        q[b] = rsqrtf(fmaxf(qq * inv - mean * mean, 0.f) + eps);
+        q[b] = rsqrtf(fmaxf(__builtin_fmaf(-mean, mean, qq * inv), 0.f) + eps);
     }
 }
 
@@ -81,6 +88,9 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f4 (&acc)[B
     // 3x3 convolution), or -1.  Slabs are a property of the output tensor, not of the tile shape: a 128-row tile emits
     // two per wave, a 64-row tile one, with the same pixels and the same summation order inside each -- so the
     // GroupNorm statistics (and everything downstream) do not depend on the launch plan or on the batch size.
+    // Every instantiation (tile shape, kernel variant, LDS- or global-resident constants) must round the same way: no
+    // compiler-chosen fused multiply-adds in here, the two that are wanted are spelled out.
+#pragma clang fp contract(off)
     constexpr int TM = BM / 32, TN = BN / 32;
     if (p.splits > 1) {   // split-K: raw fp32 partial slab, epilogue runs in splitk_reduce_kernel
         float* __restrict__ wsb = p.ws + (long long)blockIdx.y * p.M * p.N;
@@ -125,7 +135,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f4 (&acc)[B
                     f4 v = acc[a][b];
                     if (ln_mu) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = ln_r[b] * (v[j] - ln_mu[b] * lng4[j]) + lnc4[j];
+                        for (int j = 0; j < 4; ++j) v[j] = __builtin_fmaf(ln_r[b], __builtin_fmaf(-ln_mu[b], lng4[j], v[j]), lnc4[j]);
                     }
                     v[0] += bias4[0]; v[1] += bias4[1]; v[2] += bias4[2]; v[3] += bias4[3];
                     if (p.rowadd) { h4 t = *reinterpret_cast<const h4*>(p.rowadd + (long long)(m / p.rows_per_batch) * p.ld_rowadd + n);
@@ -197,8 +207,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f4 (&acc)[B
                 if (ln_mu) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        x[j] = ln_r[b] * (x[j] - ln_mu[b] * gx[j]) + cx[j];
-                        g[j] = ln_r[b] * (g[j] - ln_mu[b] * gg[j]) + cg[j];
+                        x[j] = __builtin_fmaf(ln_r[b], __builtin_fmaf(-ln_mu[b], gx[j], x[j]), cx[j]);
+                        g[j] = __builtin_fmaf(ln_r[b], __builtin_fmaf(-ln_mu[b], gg[j], g[j]), cg[j]);
                     }
                 }
                 h4 o;

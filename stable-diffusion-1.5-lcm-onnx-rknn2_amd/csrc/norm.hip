@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict_
             h8 o0, o1;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                float f0 = (float)v0[j] * sc[j] + sh[j], f1 = (float)v1[j] * sc[j] + sh[j];
+                float f0 = __builtin_fmaf((float)v0[j], sc[j], sh[j]), f1 = __builtin_fmaf((float)v1[j], sc[j], sh[j]);
                 if (silu) { f0 = silu_f(f0); f1 = silu_f(f1); }
                 o0[j] = (half_t)f0; o1[j] = (half_t)f1;
             }
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* __restrict_
             h8 o;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                float f = (float)v[j] * sc[j] + sh[j];
+                float f = __builtin_fmaf((float)v[j], sc[j], sh[j]);
                 if (silu) f = silu_f(f);
                 o[j] = (half_t)f;
             }
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256) void gn_from_stats_fused_kernel(const half_t* 
         const int pr = i / hp, j = i - pr * hp;
         const int c = c_lo + 2 * j;
         const long long row = rowbase + r0 + pr;
-        float f0 = (float)v[0] * sc_s[2 * j] + sh_s[2 * j], f1 = (float)v[1] * sc_s[2 * j + 1] + sh_s[2 * j + 1];
+        float f0 = __builtin_fmaf((float)v[0], sc_s[2 * j], sh_s[2 * j]), f1 = __builtin_fmaf((float)v[1], sc_s[2 * j + 1], sh_s[2 * j + 1]);
         if (silu) { f0 = silu_f(f0); f1 = silu_f(f1); }
         h2v o = {(half_t)f0, (half_t)f1};
         *reinterpret_cast<h2v*>(out + row * C + c) = o;

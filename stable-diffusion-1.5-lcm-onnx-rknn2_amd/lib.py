@@ -64,6 +64,7 @@ _SIGS = {
     "lcm_set_stream_workspace": [_vp, _vp, _i64],
     "lcm_set_tuning": [_i, _i, _i],
     "lcm_set_split_policy": [_i, _i],
+    "lcm_set_seg_mode": [_i],
     "lcm_set_kernel_variant": [_i],
     "lcm_set_conv_impl": [_i],
     "lcm_set_persist_n": [_i],

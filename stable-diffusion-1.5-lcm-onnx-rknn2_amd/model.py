@@ -245,7 +245,9 @@ class UNetHip(_Net):
             Wg, c = pack_geglu(Wg, c)
         Wh = Wg.to(torch.float16)
         self._put(name + ".w", Wh)
-        self._put(name + ".g", Wh.float().sum(1), torch.float32)
+        # g from the kernel that also refreshes it after a style re-merge (same summation order: weight 0 restores the bits)
+        self._put(name + ".g", torch.zeros(Wh.shape[0]), torch.float32)
+        ops.ln_fold_refresh(self.w[name + ".w"], self.w[name + ".g"])
         self._put(name + ".c", c, torch.float32)
         self._put(name + ".lnw", g32, torch.float32)
         self._put(name + ".lnb", b32, torch.float32)

@@ -372,8 +372,13 @@ def set_tuning(target_wgs=0, max_splits=0, min_wgs=0):
     _lib.check(_lib.load().lcm_set_tuning(int(target_wgs), int(max_splits), int(min_wgs)), "lcm_set_tuning")
 
 
-def set_split_policy(max_rows_per_image=1024, max_parts=4):
+def set_split_policy(max_rows_per_image=4096, max_parts=8):
     _lib.check(_lib.load().lcm_set_split_policy(int(max_rows_per_image), int(max_parts)), "lcm_set_split_policy")
+
+
+def set_seg_mode(mode):
+    """0 auto, 1 always segmented accumulation, 2 always split + reduce (bit-identical; include/lcm_hip.h)."""
+    _lib.check(_lib.load().lcm_set_seg_mode(int(mode)), "lcm_set_seg_mode")
 
 
 def set_gn_fused_bytes(n):

@@ -946,3 +946,51 @@ def test_gemm_with_folded_layernorm(M, C, N, geglu, bias):
     torch.cuda.synchronize()
     assert (g2.cpu() - g).abs().max() < 1e-4 * max(1.0, g.abs().max().item())
     assert torch.allclose(c2.cpu(), c + 0.5 * dc.cpu(), atol=1e-6)
+
+
+@pytest.mark.parametrize("kind,B,H,W,Cin,Cout,stride,ups", [("conv", 2, 16, 16, 1280, 1280, 1, 0), ("conv", 1, 32, 32, 640, 640, 1, 0),
+                                                          ("conv", 2, 16, 16, 640, 640, 1, 2), ("conv", 1, 12, 20, 256, 128, 1, 0),
+                                                          ("conv", 1, 32, 32, 320, 640, 2, 0), ("gemm", 2, 16, 16, 5120, 1280, 1, 0),
+                                                          ("gemm", 1, 32, 32, 2560, 640, 1, 0)])
+def test_segmented_accumulation_is_bit_identical_to_split(kind, B, H, W, Cin, Cout, stride, ups):
+    """A layer whose canonical K partition has several parts runs either split over workgroups (fp32 slabs + the reduce
+    launch) or segmented in one workgroup (parts accumulated separately, added in part order in registers): outputs,
+    statistics slabs and the GroupNorm downstream must be the same bits, with bias / row-add / residual epilogues."""
+    from sdlcm_amd.packing import pack_conv3x3_up2
+    Ho, Wo = (2 * H, 2 * W) if ups else ((H + 1) // 2, (W + 1) // 2) if stride == 2 else (H, W)
+    HW = Ho * Wo
+    b, radd = rnd(Cout, seed=3).to(DEV), rnd(B, Cout, seed=7).to(DEV)
+    res = rnd(B * HW, Cout, seed=8).to(DEV)
+    if kind == "conv":
+        x = to_nhwc(rnd(B, Cin, H, W, seed=1)).to(DEV)
+        w4 = rnd(Cout, Cin, 3, 3, seed=2, scale=(9 * Cin) ** -0.5)
+        w = (pack_conv3x3_up2(w4) if ups == 2 else pack3x3(w4)).to(DEV)
+        K = (4 if ups == 2 else 9) * Cin
+        nparts = ops.canonical_splits(1 if stride == 2 else 2, HW, Cout, K, (Wo << 1) if stride == 1 else 1, 1 if ups == 2 else 0)
+    else:
+        x = rnd(B * HW, Cin, seed=1).to(DEV)
+        w = rnd(Cout, Cin, seed=2, scale=Cin ** -0.5).to(DEV)
+        nparts = ops.canonical_splits(0, HW, Cout, Cin)
+    skws = torch.empty(32 << 20, dtype=torch.float32, device=DEV)
+    ops.set_workspace(skws)
+    got = []
+    try:
+        assert nparts > 1, "pick a shape whose canonical partition has parts"
+        for mode in (2, 1):
+            ops.set_seg_mode(mode)
+            o = torch.empty(B * HW, Cout, dtype=torch.float16, device=DEV)
+            st = ops.Stats(torch.zeros(ops.stats_floats(B * HW, Cout, HW), dtype=torch.float32, device=DEV))
+            if kind == "conv":
+                ops.conv3x3(x, w, o, B, H, W, Cin, Cout, bias=b, rowadd=radd, res=res, stride=stride, ups=ups, stats=st)
+            else:
+                ops.gemm(x, w, o, bias=b, rowadd=radd, rows_per_batch=HW, res=res, stats=st, img_rows=HW)
+            assert st.P > 0
+            got.append((o, st.P, st.buf[:B * st.P * Cout * 2].clone(), _gn_of(o, st, B, HW, Cout)))
+        torch.cuda.synchronize()
+    finally:
+        ops.set_seg_mode(0)
+        ops.set_workspace(None)
+    assert got[0][1] == got[1][1]
+    assert torch.equal(got[0][0], got[1][0]), "segmented output differs from split + reduce"
+    assert torch.equal(got[0][2], got[1][2]), "statistics slabs differ"
+    assert torch.equal(got[0][3], got[1][3])

@@ -74,4 +74,23 @@ for nthreads in (1, 2, 3, 4, 8, 16):
                   f"dispatcher idle between passes {1e3 * sum(gaps) / len(gaps):.1f} ms", flush=True)
     for x in ws[1:]:
         x.close()
+
+# ---- the sampler alone under concurrency (no PNG encode in the callers' loop): what the lanes buy on the GPU side.
+# Two callers, micro-batching off (LCM_MICROBATCH=1 run) or on: each caller blocks in _submit (CLIP + H2D + graph + D2H).
+for nthreads in (1, 2):
+    ws = [w] + [create_hip_worker(worker_id=i) for i in range(1, nthreads)]
+    per = 40
+    def loop2(k):
+        for i in range(per):
+            ws[k]._submit(Job(Req(seed=3000 * k + i)))
+    wu = [threading.Thread(target=lambda k=k: [ws[k]._submit(Job(Req(seed=70 + k))) for _ in range(3)]) for k in range(len(ws))]
+    [t.start() for t in wu]; [t.join() for t in wu]
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=loop2, args=(k,)) for k in range(len(ws))]
+    [t.start() for t in th]; [t.join() for t in th]
+    dt = time.perf_counter() - t0
+    print(f"sampler only (no PNG), {nthreads} callers, lanes={w._engine.n_lanes}, microbatch={os.environ.get('LCM_MICROBATCH', '8')}: "
+          f"{nthreads * per / dt:6.1f} img/s", flush=True)
+    for x in ws[1:]:
+        x.close()
 w.close()
