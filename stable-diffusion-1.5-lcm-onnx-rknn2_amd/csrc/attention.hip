@@ -32,7 +32,6 @@ struct AttnCfg {
     static constexpr int VS0 = DV * 2;
     static constexpr int VS = ((VS0 % 256) == 64 || (VS0 % 256) == 192) ? VS0 : VS0 + 64;  // tr_b16 conflict-free
     static constexpr int NCH = D / 8;                 // 16-byte chunks per row
-    static constexpr int NLD = (64 * NCH + 255) / 256;  // staged chunks per thread per tensor
     static constexpr int LDS_BYTES = 64 * KS + 64 * VS;
     // Row sums on the matrix core: when V has a padding column (DV > D) it is set to 1.0, so row D of
     // O^T = V^T P^T is sum_k P[q][k] (accumulated in fp32, rescaled together with O).  It lands in lanes 0-31,
@@ -41,9 +40,14 @@ struct AttnCfg {
     static constexpr int ONES_DB = D / 32, ONES_REG = 4 * ((D % 32) >> 3) + ((D % 32) & 3);
 };
 
-template <int D>
-__global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
+// WAVES = 4: 128 query rows per workgroup; WAVES = 2: 64 rows -- twice the workgroups for launches that would otherwise put
+// at most one workgroup on a CU (batch-1 self-attention at S = 4096: 256 workgroups on 256 CUs, one wave per SIMD, nothing
+// to overlap the softmax VALU and the K/V staging with).  A query row's arithmetic does not depend on the split: same bits.
+template <int D, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void attn_kernel(AttnParams p) {
     using C = AttnCfg<D>;
+    constexpr int NT = 64 * WAVES;                      // threads
+    constexpr int NLD = (64 * C::NCH + NT - 1) / NT;    // staged chunks per thread per tensor
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem;
     char* Vs = smem + 64 * C::KS;
@@ -51,7 +55,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hh = lane >> 5;
     const int bh = blockIdx.y, b = bh / p.heads, head = bh - b * p.heads;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = blockIdx.x * (32 * WAVES) + wave * 32;
     const int qrow = q0 + l31;
 
     const half_t* Qb = p.Q + (long long)b * p.Sq * p.ldq + head * D;
@@ -59,7 +63,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
     const half_t* Vb = p.V + (long long)b * p.Sk * p.ldv + head * D;
 
     // zero LDS once: pad columns (d >= D) must read as 0
-    for (int i = tid * 16; i < C::LDS_BYTES; i += 256 * 16) *reinterpret_cast<f4*>(smem + i) = (f4){0.f, 0.f, 0.f, 0.f};
+    for (int i = tid * 16; i < C::LDS_BYTES; i += NT * 16) *reinterpret_cast<f4*>(smem + i) = (f4){0.f, 0.f, 0.f, 0.f};
     if (C::ONES) {
         __syncthreads();
         if (tid < 64) *reinterpret_cast<half_t*>(Vs + tid * C::VS + D * 2) = (half_t)1.0f;   // never overwritten: tiles fill cols < D
@@ -75,11 +79,11 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
         qf[ks] = v;
     }
 
-    h8 rk[C::NLD], rv[C::NLD];
+    h8 rk[NLD], rv[NLD];
     auto load_tile = [&](int t) {
 #pragma unroll
-        for (int i = 0; i < C::NLD; ++i) {
-            const int idx = tid + 256 * i;
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = tid + NT * i;
             h8 a = {0, 0, 0, 0, 0, 0, 0, 0}, c = {0, 0, 0, 0, 0, 0, 0, 0};
             if (idx < 64 * C::NCH) {
                 const int r = idx / C::NCH, ch = idx - r * C::NCH;
@@ -94,8 +98,8 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
     };
     auto store_tile = [&]() {
 #pragma unroll
-        for (int i = 0; i < C::NLD; ++i) {
-            const int idx = tid + 256 * i;
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = tid + NT * i;
             if (idx < 64 * C::NCH) {
                 const int r = idx / C::NCH, ch = idx - r * C::NCH;
                 *reinterpret_cast<h8*>(Ks + r * C::KS + ch * 16) = rk[i];
@@ -195,7 +199,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
     const bool ragged = (p.Sk & 63) != 0;
     for (int t = 0; t < ntiles; ++t) {
         // masked code path: the ragged last tile, and (causal) every tile that reaches past this workgroup's first query
-        if ((ragged && t == ntiles - 1) || (p.causal && t * 64 + 63 > (int)blockIdx.x * 128)) tile_body(t, std::true_type{});
+        if ((ragged && t == ntiles - 1) || (p.causal && t * 64 + 63 > (int)blockIdx.x * (32 * WAVES))) tile_body(t, std::true_type{});
         else tile_body(t, std::false_type{});
     }
 
@@ -220,23 +224,39 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
     }
 }
 
-template <int D>
-static int launch_attn(const AttnParams& p, hipStream_t s) {
+static int g_attn_waves = 0;      // 0: by grid size; 2 / 4: forced (tests)
+extern "C" int lcm_set_attention_waves(int waves) {
+    if (waves != 0 && waves != 2 && waves != 4) { lcm_set_error("attention_waves: %d", waves); return LCM_EINVAL; }
+    g_attn_waves = waves;
+    return LCM_OK;
+}
+
+template <int D, int WAVES>
+static int launch_attn_w(const AttnParams& p, hipStream_t s) {
     using C = AttnCfg<D>;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<D>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<D, WAVES>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
         attr_set = true;
     }
-    dim3 grid((p.Sq + 127) / 128, p.B * p.heads);
+    dim3 grid((p.Sq + 32 * WAVES - 1) / (32 * WAVES), p.B * p.heads);
     char nm[32];
-    snprintf(nm, sizeof(nm), "attn_kernel<%d>", D);
+    snprintf(nm, sizeof(nm), "attn_kernel<%d, %d>", D, WAVES);
     lcm_prof_start(nm, s);
-    hipLaunchKernelGGL((attn_kernel<D>), grid, dim3(256), C::LDS_BYTES, s, p);
+    hipLaunchKernelGGL((attn_kernel<D, WAVES>), grid, dim3(64 * WAVES), C::LDS_BYTES, s, p);
     lcm_prof_stop(s);
     LCM_CHECK_LAUNCH("attention");
     return LCM_OK;
+}
+
+template <int D>
+static int launch_attn(const AttnParams& p, hipStream_t s) {
+    // 64-row workgroups when 128-row ones would leave CUs with at most one workgroup (and there are enough keys for the
+    // second workgroup's K/V re-read to be worth it)
+    const long long wgs128 = (long long)((p.Sq + 127) / 128) * p.B * p.heads;
+    const bool two = g_attn_waves ? g_attn_waves == 2 : (wgs128 <= 384 && p.Sq >= 128 && p.Sk >= 256);
+    return two ? launch_attn_w<D, 2>(p, s) : launch_attn_w<D, 4>(p, s);
 }
 
 extern "C" int lcm_attention_f16(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* out,

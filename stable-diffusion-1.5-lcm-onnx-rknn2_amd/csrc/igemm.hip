@@ -302,16 +302,17 @@ __global__ __launch_bounds__(256, S == 1 ? (BM + BN < 256 ? 4 : 3) : 2) void ige
 #pragma unroll
     for (int b = 0; b < TM; ++b) { ln_s[b] = 0.f; ln_q[b] = 0.f; }
 
+#pragma unroll
+    for (int s = 0; s < S - 1; ++s)
+        if (s < T) issue_tile(s, s);
     const __attribute__((address_space(3))) float* ln_lds = nullptr;
-    if constexpr (ln) {       // this n-tile's ln_g | ln_c into LDS (behind the ring's stages) before any LDS-DMA is in flight
+    if constexpr (ln) {       // this n-tile's ln_g | ln_c into LDS (behind the ring's stages), outside the K loop and under
+                              // the latency of the first tiles just issued
         float* t = reinterpret_cast<float*>(smem + S * BUF);
         if (tid < BN) { t[tid] = p.ln_g[nt0 * BN + tid]; t[BN + tid] = p.ln_c[nt0 * BN + tid]; }
         __syncthreads();
         ln_lds = (const __attribute__((address_space(3))) float*)t;
     }
-#pragma unroll
-    for (int s = 0; s < S - 1; ++s)
-        if (s < T) issue_tile(s, s);
 
     f4 tot[SEG ? TN : 1][SEG ? TM : 1];
     int part = 0, nkp = nkr;               // SEG: k-tiles of the current part

@@ -376,6 +376,10 @@ def set_split_policy(max_rows_per_image=4096, max_parts=8):
     _lib.check(_lib.load().lcm_set_split_policy(int(max_rows_per_image), int(max_parts)), "lcm_set_split_policy")
 
 
+def set_attention_waves(waves):
+    _lib.check(_lib.load().lcm_set_attention_waves(int(waves)), "lcm_set_attention_waves")
+
+
 def set_seg_mode(mode):
     """0 auto, 1 always segmented accumulation, 2 always split + reduce (bit-identical; include/lcm_hip.h)."""
     _lib.check(_lib.load().lcm_set_seg_mode(int(mode)), "lcm_set_seg_mode")

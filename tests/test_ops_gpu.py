@@ -949,7 +949,7 @@ def test_gemm_with_folded_layernorm(M, C, N, geglu, bias):
 
 
 @pytest.mark.parametrize("kind,B,H,W,Cin,Cout,stride,ups", [("conv", 2, 16, 16, 1280, 1280, 1, 0), ("conv", 1, 32, 32, 640, 640, 1, 0),
-                                                          ("conv", 2, 16, 16, 640, 640, 1, 2), ("conv", 1, 12, 20, 256, 128, 1, 0),
+                                                          ("conv", 2, 16, 16, 1280, 1280, 1, 2), ("conv", 1, 12, 20, 512, 128, 1, 0),
                                                           ("conv", 1, 32, 32, 320, 640, 2, 0), ("gemm", 2, 16, 16, 5120, 1280, 1, 0),
                                                           ("gemm", 1, 32, 32, 2560, 640, 1, 0)])
 def test_segmented_accumulation_is_bit_identical_to_split(kind, B, H, W, Cin, Cout, stride, ups):
@@ -994,3 +994,26 @@ def test_segmented_accumulation_is_bit_identical_to_split(kind, B, H, W, Cin, Co
     assert torch.equal(got[0][0], got[1][0]), "segmented output differs from split + reduce"
     assert torch.equal(got[0][2], got[1][2]), "statistics slabs differ"
     assert torch.equal(got[0][3], got[1][3])
+
+
+@pytest.mark.parametrize("B,heads,Sq,Sk,d,causal", [(1, 8, 4096, 4096, 40, False), (2, 8, 1024, 1024, 80, False), (1, 8, 3185, 3185, 40, False),
+                                                  (1, 8, 256, 77, 160, False), (2, 12, 77, 77, 64, True)])
+def test_attention_workgroup_shape_is_bit_neutral(B, heads, Sq, Sk, d, causal):
+    """64-row (2 waves) and 128-row (4 waves) attention workgroups: a query row's online softmax walks the same K/V tiles in
+    the same order either way, so the choice (made from the grid size, i.e. from the batch) never changes a bit."""
+    C = heads * d
+    q, k, v = (rnd(B * S, C, seed=i + 1).to(DEV) for i, S in enumerate((Sq, Sk, Sk)))
+    outs = []
+    try:
+        for waves in (4, 2, 0):
+            ops.set_attention_waves(waves)
+            o = torch.empty(B * Sq, C, dtype=torch.float16, device=DEV)
+            ops.attention(q, k, v, o, B, heads, Sq, Sk, d, ldq=C, ldk=C, ldv=C, ldo=C, causal=causal)
+            outs.append(o)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_attention_waves(0)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    qf, kf, vf = (t.float().cpu().reshape(B, -1, heads, d).transpose(1, 2) for t in (q, k, v))
+    ref = F.scaled_dot_product_attention(qf, kf, vf, is_causal=causal).transpose(1, 2).reshape(B * Sq, C)
+    close(outs[0], ref, what="attention")
