@@ -213,8 +213,8 @@ int lcm_layernorm_f16(const void* x, const void* gamma, const void* beta, void* 
  */
 int lcm_attention_f16(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* out, int ldo,
                       int B, int heads, int Sq, int Sk, int d, float scale, int causal, void* stream);
-/* query rows per attention workgroup: 0 (default) = 64 when 128-row workgroups would leave the CUs with at most one
- * workgroup each (batch-1 self-attention), else 128; 2 / 4 force 64 / 128 (waves per workgroup).  Bit-neutral. */
+/* query rows per attention workgroup: 0 / 4 = 128 (default), 2 = 64 (twice the workgroups; measured slower at batch 1:
+ * every workgroup re-stages all K/V tiles).  Bit-neutral. */
 int lcm_set_attention_waves(int waves);
 /* causal != 0: keys after the query are masked (CLIPTextModel's causal attention mask, transformers; the text
  * encoder call of the pipeline, twin backends/rknnlcm.py:266-367). */

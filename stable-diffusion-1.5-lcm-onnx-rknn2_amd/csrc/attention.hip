@@ -40,9 +40,8 @@ struct AttnCfg {
     static constexpr int ONES_DB = D / 32, ONES_REG = 4 * ((D % 32) >> 3) + ((D % 32) & 3);
 };
 
-// WAVES = 4: 128 query rows per workgroup; WAVES = 2: 64 rows -- twice the workgroups for launches that would otherwise put
-// at most one workgroup on a CU (batch-1 self-attention at S = 4096: 256 workgroups on 256 CUs, one wave per SIMD, nothing
-// to overlap the softmax VALU and the K/V staging with).  A query row's arithmetic does not depend on the split: same bits.
+// WAVES = 4: 128 query rows per workgroup (the form used); WAVES = 2: 64 rows, twice the workgroups (kept as a switch: it
+// measured slower, see launch_attn).  A query row's arithmetic does not depend on the split: same bits.
 template <int D, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void attn_kernel(AttnParams p) {
     using C = AttnCfg<D>;
@@ -252,11 +251,11 @@ static int launch_attn_w(const AttnParams& p, hipStream_t s) {
 
 template <int D>
 static int launch_attn(const AttnParams& p, hipStream_t s) {
-    // 64-row workgroups when 128-row ones would leave CUs with at most one workgroup (and there are enough keys for the
-    // second workgroup's K/V re-read to be worth it)
-    const long long wgs128 = (long long)((p.Sq + 127) / 128) * p.B * p.heads;
-    const bool two = g_attn_waves ? g_attn_waves == 2 : (wgs128 <= 384 && p.Sq >= 128 && p.Sk >= 256);
-    return two ? launch_attn_w<D, 2>(p, s) : launch_attn_w<D, 4>(p, s);
+    // 128-row workgroups.  Measured at batch 1, S = 4096, d = 40 (256 workgroups of 128 rows, one per CU): 64-row workgroups
+    // (512, two per CU) take 104 us against 70 us -- every workgroup re-stages all 64 K/V tiles, and that staging (not the
+    // MFMA or the softmax) is what a workgroup's time is made of.  (Double-buffering the K/V tiles in LDS -- one barrier per
+    // tile instead of two -- was measured too: -5 % at batch 8, +20 % at batch 1; not kept.)  The 64-row form stays selectable.
+    return g_attn_waves == 2 ? launch_attn_w<D, 2>(p, s) : launch_attn_w<D, 4>(p, s);
 }
 
 extern "C" int lcm_attention_f16(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* out,
