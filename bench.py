@@ -227,15 +227,15 @@ def main():
 
     bcast_ms = {}
 
-    def prime(Bx):
+    def prime(Bx, lane=0):
         """Fill a plan's resident inputs: embeddings broadcast from rank 0 over RCCL, per-request noise."""
-        P = pipe.plan(Bx, h, w, n)
-        with torch.cuda.stream(pipe.stream):
+        P = pipe.plan(Bx, h, w, n, lane=lane)
+        with torch.cuda.stream(P.lane.stream):
             allpe = torch.empty(world * Bx, 77, D, dtype=torch.float16, device=dev)
             if rank == 0:
                 allpe.copy_(torch.randn(world * Bx, 77, D, generator=torch.Generator().manual_seed(1)).half())
             if dist is not None:
-                pipe.stream.synchronize()
+                P.lane.stream.synchronize()
                 for rep in range(2):                  # first call sets the communicator up; the second is the exchange itself
                     dist.barrier()
                     torch.cuda.synchronize()
@@ -262,13 +262,29 @@ def main():
             P.wemb.copy_(torch.from_numpy(guidance_scale_embedding(np.zeros(Bx, np.float32), P.wemb.shape[1])).half())
             pipe.tune(P)                               # per-shape launch autotune (once)
             pipe._enqueue(P, 1.0)                      # eager warm-up: allocates scratch
-            pipe.stream.synchronize()
+            P.lane.stream.synchronize()
             from sdlcm_amd import ops
             g = ops.Graph()
             with g:
                 pipe._enqueue(P, 1.0)
             P.graph = g
         return P
+
+    def timed_lanes(Ps, K, W):
+        """K passes per lane with one pass of every lane in flight at a time (the serving mode at low load, DESIGN.md
+        section 6): every lane replays its own graph on its own stream; -> (seconds, passes)."""
+        for _ in range(W):
+            for P in Ps:
+                with torch.cuda.stream(P.lane.stream):
+                    P.graph.launch()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(K):
+            for P in Ps:
+                with torch.cuda.stream(P.lane.stream):
+                    P.graph.launch()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, K * len(Ps)
 
     def timed(P, K, W):
         with torch.cuda.stream(pipe.stream):
@@ -332,6 +348,12 @@ def main():
                                     "pipeline_tflops": round(fl_img * 8 / (dt8 / k8) / 1e12, 1),
                                     "workload": "same, batch 8 per GPU (BASELINE configs[2] per-GPU shard)",
                                     "roofline": roofline_leg(pipe, P8, 1.0, dt8 / k8 * 1e3)}
+        if not args.no_extra and B == 1 and args.model == "sd15":
+            P1 = prime(1, lane=1)
+            dtl, npass = timed_lanes([P, P1], args.steps, 2)
+            line["extra_two_lanes"] = {"images_per_s": round(npass / dtl, 2), "ms_per_image_per_lane": round(dtl / args.steps * 1e3, 2),
+                                       "workload": "same batch-1 requests, two in flight on two lanes of the pipeline (own stream / scratch / "
+                                                   "graph / split-K workspace, shared weights); never `value`"}
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(host_threads())
     if rank == 0:
