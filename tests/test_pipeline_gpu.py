@@ -258,6 +258,24 @@ def test_two_lanes_in_flight_match_solo_runs(state):
         assert np.array_equal(rgb, solo[i]["rgb"]) and np.array_equal(lat, solo[i]["latents"]), (lane, rep, i)
 
 
+def test_graphs_of_earlier_plans_survive_larger_plans(state):
+    """A captured hipGraph bakes raw pointers in.  Building and running a batch-8 plan (bigger GroupNorm workspaces, scratch,
+    statistics buffers) after a batch-1 plan must not free or move anything the batch-1 graph still uses: the batch-1
+    request replays to the same bytes afterwards (round 1 grew one shared GroupNorm workspace in place)."""
+    hip = state["hip"]
+    pe1, pe8 = _embeds(1, seed=51), _embeds(8, seed=52)
+    first = hip.generate(pe1, [31], 256, 256, 2, 1.0)
+    assert hip.plan(1, 32, 32, 2).graph is not None
+    big = hip.generate(pe8, list(range(40, 48)), 256, 256, 2, 1.0)
+    junk = [torch.full((1 << 22,), 7.0, device=hip.device) for _ in range(8)]      # would land in anything that was freed
+    torch.cuda.synchronize()
+    again = hip.generate(pe1, [31], 256, 256, 2, 1.0)
+    del junk
+    assert np.array_equal(again["rgb"], first["rgb"]) and np.array_equal(again["latents"], first["latents"])
+    big2 = hip.generate(pe8, list(range(40, 48)), 256, 256, 2, 1.0)
+    assert np.array_equal(big2["rgb"], big["rgb"])
+
+
 def test_latents_blob_matches_oracle_pooling(state):
     from oracle import glue
     hip = state["hip"]
