@@ -31,6 +31,10 @@ UPS_PHASES = os.environ.get("LCM_UPS_PHASES", "1") != "0"
 # LayerNorm folded into the GEMM that consumes it (norm1 -> q|k|v, norm2 -> attn2.to_q, norm3 -> GEGLU proj): 192 launches
 # fewer per 512x512 4-step pass, no LayerNorm output in HBM (ops.gemm_ln / lcm_gemm_ln_f16)
 LN_FOLD = os.environ.get("LCM_LN_FOLD", "1") != "0"
+# conv_shortcut of a ResnetBlock2D on a forked side stream, concurrent with norm1 -> conv1 -> norm2 (see _Net.resnet).
+# OFF by default: measured on the same box, 512x512 4-step batch 1: 45.5 images/s with the 56 fork / join pairs per pass in
+# the captured graph against 47.6 without -- a cross-stream edge costs more here than the ~10 us GEMM it takes off the chain.
+FORK_SHORTCUT = os.environ.get("LCM_FORK_SHORTCUT", "0") != "0"
 FUSE_GN_CONV = os.environ.get("LCM_FUSE_GN_CONV", "1") != "0"
 FUSE_GN_MIN_BYTES = int(os.environ.get("LCM_FUSE_GN_MIN_BYTES", str(64 << 20)))
 
@@ -70,6 +74,7 @@ class _Net:
         self.w = {}
         self.buf = _Buffers(device)
         self._stats = {}
+        self.side_stream = None       # set by the pipeline lane: a second stream for launches that fork off the main chain
 
     def _put(self, name, t, dtype=torch.float16):
         self.w[name] = _dev(t, self.device, dtype)
@@ -136,6 +141,23 @@ class _Net:
         HW, M, Cin = H * W, B * H * W, C1 + C2
         w = self.w
         have1 = x_st is not None and x_st.P > 0 and (x2 is None or (x2_st is not None and x2_st.P > 0))
+        # conv_shortcut (1x1 over the raw input) does not depend on norm1 -> conv1 -> norm2: with LCM_FORK_SHORTCUT=1 it forks
+        # onto the lane's side stream and joins before conv2 adds it as the residual (edges of the captured graph).  Measured
+        # slower than the serial chain (see FORK_SHORTCUT), so off by default.
+        sc, join = x, None
+        if (p + ".sc.w") in w:
+            sc = self.buf.get("shortcut", M, Cout)
+            side = self.side_stream if FORK_SHORTCUT else None
+            if side is not None:
+                fork = torch.cuda.Event()
+                fork.record()
+                with torch.cuda.stream(side):
+                    side.wait_event(fork)
+                    ops.gemm(x, w[p + ".sc.w"], sc, bias=w[p + ".sc.b"], a2=x2, img_rows=HW)
+                    join = torch.cuda.Event()
+                    join.record()
+            else:
+                ops.gemm(x, w[p + ".sc.w"], sc, bias=w[p + ".sc.b"], a2=x2, img_rows=HW)
         h1 = self.buf.get("conv1", M, Cout)
         h1_st = self.stats("conv1", M, Cout, HW)
         if have1 and C1 % 64 == 0 and C2 % 64 == 0 and _fuse_gn_into_conv(M, Cin, Cout):
@@ -147,21 +169,20 @@ class _Net:
             hn = self.buf.get("gn", M, Cin)
             self.norm(x, w[p + ".norm1.g"], w[p + ".norm1.b"], hn, B, HW, C1, x_st=x_st, x2=x2, C2=C2, x2_st=x2_st, eps=eps)
             ops.conv3x3(hn, w[p + ".conv1.w"], h1, B, H, W, Cin, Cout, bias=w[p + ".conv1.b"], rowadd=rowadd, stats=h1_st)
-        if (p + ".sc.w") in w:
-            sc = self.buf.get("shortcut", M, Cout)
-            ops.gemm(x, w[p + ".sc.w"], sc, bias=w[p + ".sc.b"], a2=x2, img_rows=HW)
-        else:
-            sc = x
         out = self.buf.get(out_role, M, Cout)
         out_st = self.stats(out_role, M, Cout, HW)
         if h1_st.P > 0 and _fuse_gn_into_conv(M, Cout, Cout):
             sc_t, sh_t = ops.groupnorm_tables_from_stats(w[p + ".norm2.g"], w[p + ".norm2.b"], B, HW, Cout, h1_st,
                                                          self.gn_ws(B, HW, Cout), eps=eps)
+            if join is not None:
+                torch.cuda.current_stream().wait_event(join)
             ops.conv3x3_gn(h1, w[p + ".conv2.w"], out, B, H, W, Cout, Cout, gn_scale=sc_t, gn_shift=sh_t, silu=True,
                            bias=w[p + ".conv2.b"], res=sc, stats=out_st)
         else:
             hn2 = self.buf.get("gn", M, Cout)
             self.norm(h1, w[p + ".norm2.g"], w[p + ".norm2.b"], hn2, B, HW, Cout, x_st=h1_st, eps=eps)
+            if join is not None:
+                torch.cuda.current_stream().wait_event(join)
             ops.conv3x3(hn2, w[p + ".conv2.w"], out, B, H, W, Cout, Cout, bias=w[p + ".conv2.b"], res=sc, stats=out_st)
         return out, out_st
 

@@ -55,9 +55,11 @@ def draw_noise(seed: int, h: int, w: int, n_extra: int, sigma: float = 1.0):
 _WS = {}
 
 
-def _splitk_workspace(device, lane=0):
+def _splitk_workspace(device, lane=0, mb=None):
     key = (device.type, device.index if device.index is not None else torch.cuda.current_device(), lane)
     t = _WS.get(key)
+    if t is None and mb is not None:
+        t = _WS[key] = torch.empty(int(mb) << 18, dtype=torch.float32, device=device)
     if t is None:
         # sized for a batch of 8 at 768x768 (472 MB) / SDXL 1024x1024 (fp32 [splits][M][N] of the largest split layer); a launch
         # that needs more fails loudly (a silently smaller split factor would change the numbers)
@@ -81,6 +83,13 @@ class _Lane:
         # per (device, lane) and outlive every pipeline / captured graph that may still launch with them.
         self.splitk_ws = _splitk_workspace(pipe.device, index)
         ops.set_stream_workspace(self.stream, self.splitk_ws)
+        # side stream: launches that fork off the main chain inside one pass (the resnets' conv_shortcut GEMMs), with a
+        # split-K workspace of its own -- they run concurrently with the main stream's split layers
+        self.side = torch.cuda.Stream(device=pipe.device)
+        self.side_ws = _splitk_workspace(pipe.device, ("side", index), mb=256)
+        ops.set_stream_workspace(self.side, self.side_ws)
+        self.unet.side_stream = self.side
+        self.vae.side_stream = self.side
 
 
 class _Plan:
