@@ -164,6 +164,10 @@ int lcm_groupnorm_affine_f16(const void* x, int C1, const void* x2, int C2, cons
 /* launches of the LDS-halo conv with fewer workgroups than this use its pipelined variant (3-stage weight ring,
  * double-buffered halo) instead of the single-buffer high-occupancy one; default 768 */
 int lcm_set_halo_pipe_threshold(int wgs);
+/* 16x16-pixel (256-row) x 128-channel tile of the LDS-halo conv for unsplit launches on 16-wide patch grids: mode 0 off,
+ * 1 in place of the 128-row tile when the launch still has >= min_tiles workgroups (default 1024), 2 wherever N % 128 == 0.
+ * A launch parameter: never changes a bit (same K walk per output, canonical statistics slabs). */
+int lcm_set_halo_bm256(int mode, int min_tiles);
 /* 1 (default): stride-1 3x3 convolutions use the LDS-halo kernel; 0: the row-gather implicit GEMM everywhere */
 int lcm_set_conv_impl(int impl);
 
@@ -209,7 +213,10 @@ int lcm_layernorm_f16(const void* x, const void* gamma, const void* beta, void* 
 
 /* ---- fused attention softmax(scale*Q K^T) V (Attention in BasicTransformerBlock.attn1/attn2) ----
  * Q: rows b*Sq+s, element (h*d + i) at Q[row*ldq + ...]; K,V likewise with Sk rows per batch; out [B*Sq][ldo].
- * d % 8 == 0, d <= 160.  Online softmax in fp32, no S x S matrix in memory.
+ * d in {40, 64, 80, 160} (UNet / CLIP heads: 32x32x16-MFMA kernel, O for the whole head in registers) or, without causal
+ * mask, d in {256, 512} (AutoencoderKL mid-block attention, one head of 512: 16x16x32-MFMA kernel, 16 query rows per wave,
+ * V^T fragments by ds_read_b64_tr_b16).  Online softmax in fp32, no S x S matrix in memory; a query row's result does not
+ * depend on B or on the other rows.
  */
 int lcm_attention_f16(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* out, int ldo,
                       int B, int heads, int Sq, int Sk, int d, float scale, int causal, void* stream);

@@ -15,6 +15,7 @@
 //   * K/V tiles are register-staged one tile ahead (loads issued before the MFMAs of the current tile).
 #include "common.h"
 #include <type_traits>
+#include <utility>
 
 struct AttnParams {
     const half_t* Q; const half_t* K; const half_t* V; half_t* O;
@@ -258,6 +259,228 @@ static int launch_attn(const AttnParams& p, hipStream_t s) {
     return g_attn_waves == 2 ? launch_attn_w<D, 2>(p, s) : launch_attn_w<D, 4>(p, s);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Wide-head flash attention (head_dim 512): the AutoencoderKL mid-block attention (one head, d = 512, S = h*w).
+// The 32x32 kernel above keeps O for all of d in registers (d <= 160); here a wave owns 16 query rows and uses
+// v_mfma_f32_16x16x32_f16, so O^T (d x 16 queries) is d/16 accumulator quads = 128 VGPRs and Q (16 x d) 64.
+//   * S^T = K Q^T per 16-key block: A = K rows from LDS (ds_read_b128), B = Q rows held in registers; a lane owns one query
+//     column (lane & 15) and keys 4fq..4fq+3 of each block, so the online-softmax state is a per-lane scalar (max joined
+//     across the 4 lane groups of a query by two shuffles).
+//   * P^T never leaves registers: the accumulators of two key blocks, converted to fp16, ARE the B operand (32 key slots x
+//     16 queries) of O^T += V^T P^T; slot (fq, j) <-> key 4fq + j (j < 4) / 16 + 4fq + j - 4.
+//   * V stays row-major in LDS ([key][d]); the V^T A-fragment with exactly that slot order is two ds_read_b64_tr_b16
+//     (4 keys x 16 d each, hardware transpose).
+//   * K/V tiles (32 keys: 32 KB each) arrive by LDS-DMA (global_load_lds_dwordx4: a 1 KB row = one wave instruction, so rows
+//     can carry their conflict-free padding) into a DOUBLE buffer: tile t+1 is in flight during all of tile t, one barrier
+//     per tile, no staging registers and no ds_write pass (ds_write_b128 moves ~79 B/clk/CU: 830 cycles per tile here).
+//   * row stride 2d + 32 B for both: 16 * (2 mod 16) makes ds_read_b128 of the 16x16x32 A-fragment pattern (lane groups
+//     {0-3,12-15,20-27}, ...) conflict-free, 8 * (4 mod 32) the transposed reads.
+//   * with one wave per SIMD nothing hides LDS latency but the code itself: fragment reads run 8 ahead of their MFMAs.
+// No S x S matrix in memory (the GEMM -> softmax -> transpose -> GEMM form needs B * S^2 * 2 bytes: 512 MB per image at
+// SDXL's 128^2 latent).  One workgroup = 64 query rows of one (image, head); 132 KB of LDS.
+// ------------------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void attn_wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int OFF>
+__device__ __forceinline__ s4 attn_tr_read(unsigned lds_addr) {
+    s4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "n"(OFF));
+    return v;
+}
+template <int... I, class F>
+__device__ __forceinline__ void attn_static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void attn_static_for(F&& f) {
+    attn_static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
+
+template <int D, int TK>
+__global__ __launch_bounds__(256, 1) void attn_wide_kernel(AttnParams p) {
+    static_assert(D == 512 && TK == 32, "one LDS-DMA instruction per 1 KB row; 8 rows of K and of V per wave per tile");
+    constexpr int RS = D * 2 + 32;                      // row stride of K and V tiles
+    constexpr int NKS = D / 32, NDB = D / 16, NKB = TK / 16;
+    constexpr int TILE = TK * RS, BUF = 2 * TILE;       // K tile | V tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int frow = lane & 15, fq = lane >> 4;
+    const int bh = blockIdx.y, b = bh / p.heads, head = bh - b * p.heads;
+    const int qrow = blockIdx.x * 64 + wave * 16 + frow;
+    const half_t* Qb = p.Q + (long long)b * p.Sq * p.ldq + head * D;
+    const half_t* Kb = p.K + (long long)b * p.Sk * p.ldk + head * D + lane * 8;
+    const half_t* Vb = p.V + (long long)b * p.Sk * p.ldv + head * D + lane * 8;
+
+    // rows past Sk re-read the last real row (finite values; their scores are masked and P = 0)
+    auto issue_tile = [&](int t, int buf) {
+        char* ks = smem + buf * BUF + wave * (TK / 4) * RS;
+#pragma unroll
+        for (int i = 0; i < TK / 4; ++i) {
+            const int key = t * TK + wave * (TK / 4) + i;
+            const int kc = key < p.Sk ? key : p.Sk - 1;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Kb + (long long)kc * p.ldk),
+                                             (__attribute__((address_space(3))) void*)(ks + i * RS), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Vb + (long long)kc * p.ldv),
+                                             (__attribute__((address_space(3))) void*)(ks + TILE + i * RS), 16, 0, 0);
+        }
+    };
+    const int ntiles = (p.Sk + TK - 1) / TK;
+    issue_tile(0, 0);
+
+    h8 qf[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (qrow < p.Sq) v = *reinterpret_cast<const h8*>(Qb + (long long)qrow * p.ldq + 32 * ks + 8 * fq);
+        qf[ks] = v;
+    }
+    f4 oacc[NDB];
+#pragma unroll
+    for (int i = 0; i < NDB; ++i) oacc[i] = (f4){0.f, 0.f, 0.f, 0.f};
+    float m_run = -1.0e30f, l_run = 0.f;
+
+    const int k_addr = frow * RS + fq * 16;                                    // + kb*16*RS + ks*64
+    const int v_addr = TILE + (4 * fq + (frow >> 2)) * RS + (4 * (frow & 3)) * 2;   // + kb*16*RS + db*32
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1;
+        attn_wait_vmcnt<0>();                 // this wave's rows of tile t have landed (tile t+1 is not issued yet)
+        __builtin_amdgcn_s_barrier();         // everyone's have; everyone is done reading the other buffer (tile t-1)
+        if (t + 1 < ntiles) issue_tile(t + 1, buf ^ 1);
+        const char* Ks = smem + buf * BUF;
+
+        // S^T = K Q^T: the 8 K fragments of group g+1 are in flight while group g's MFMAs run
+        f4 sacc[NKB];
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) sacc[kb] = (f4){0.f, 0.f, 0.f, 0.f};
+        {
+            constexpr int G = 8 / NKB, NG = NKS / G;
+            h8 kfr[2][8];
+            auto rd = [&](int g, h8* dst) {
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                    for (int j = 0; j < G; ++j)
+                        dst[kb * G + j] = *reinterpret_cast<const h8*>(Ks + k_addr + kb * 16 * RS + (g * G + j) * 64);
+            };
+            rd(0, kfr[0]);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                if (g + 1 < NG) rd(g + 1, kfr[(g + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < G; ++j)
+#pragma unroll
+                    for (int kb = 0; kb < NKB; ++kb)
+                        sacc[kb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kfr[g & 1][kb * G + j], qf[g * G + j], sacc[kb], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (t == ntiles - 1 && (p.Sk % TK)) {           // ragged last tile
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (t * TK + kb * 16 + 4 * fq + j >= p.Sk) sacc[kb][j] = -1.0e30f;
+        }
+        float mt = -1.0e30f;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mt = fmaxf(mt, sacc[kb][j]);
+        mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        const float m_new = fmaxf(m_run, mt * p.sc);
+        if (!__all(m_new == m_run)) {
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < NDB; ++i) { oacc[i][0] *= alpha; oacc[i][1] *= alpha; oacc[i][2] *= alpha; oacc[i][3] *= alpha; }
+            m_run = m_new;
+        }
+        h8 pf[NKB / 2];
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float pv = __builtin_amdgcn_exp2f(sacc[kb][j] * p.sc - m_run);
+                l_run += pv;
+                pf[kb >> 1][(kb & 1) * 4 + j] = (half_t)pv;
+            }
+        // O^T += V^T P^T: 8 transposed reads (4 d-blocks) ahead of the MFMAs that consume them.  The reads and their
+        // counted waits are inline asm: through the builtin the compiler cannot tell these reads from the LDS-DMA writes of
+        // tile t+1 in flight (other buffer) and drains the DMA (s_waitcnt vmcnt(0)) in the middle of every tile.
+        {
+            static_assert(NKB == 2, "one key pair per tile");
+            constexpr int GD = 4, NG = NDB / GD;
+            s4 vfr[2][2 * GD];
+            const unsigned vbase = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)(Ks + v_addr);
+            attn_static_for<GD>([&](auto j) {
+                constexpr int J = decltype(j)::value;
+                vfr[0][2 * J] = attn_tr_read<J * 32>(vbase);
+                vfr[0][2 * J + 1] = attn_tr_read<J * 32 + 16 * RS>(vbase);
+            });
+            attn_static_for<NG>([&](auto g) {
+                constexpr int Gi = decltype(g)::value;
+                s4* cur = vfr[Gi & 1];
+                if constexpr (Gi + 1 < NG) {
+                    s4* nxt = vfr[(Gi + 1) & 1];
+                    attn_static_for<GD>([&](auto j) {
+                        constexpr int J = decltype(j)::value;
+                        nxt[2 * J] = attn_tr_read<((Gi + 1) * GD + J) * 32>(vbase);
+                        nxt[2 * J + 1] = attn_tr_read<((Gi + 1) * GD + J) * 32 + 16 * RS>(vbase);
+                    });
+                    asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]),
+                                 "+v"(cur[4]), "+v"(cur[5]), "+v"(cur[6]), "+v"(cur[7]));
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]),
+                                 "+v"(cur[4]), "+v"(cur[5]), "+v"(cur[6]), "+v"(cur[7]));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < GD; ++j) {
+                    const h4 lo_h = __builtin_bit_cast(h4, cur[2 * j]), hi_h = __builtin_bit_cast(h4, cur[2 * j + 1]);
+                    const h8 vf = {lo_h[0], lo_h[1], lo_h[2], lo_h[3], hi_h[0], hi_h[1], hi_h[2], hi_h[3]};
+                    oacc[Gi * GD + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[0], oacc[Gi * GD + j], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        }
+    }
+    float l_tot = l_run + __shfl_xor(l_run, 16, 64);
+    l_tot += __shfl_xor(l_tot, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (qrow < p.Sq) {
+        half_t* orow = p.O + ((long long)b * p.Sq + qrow) * p.ldo + head * D;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) {
+            h4 o = {(half_t)(oacc[db][0] * inv), (half_t)(oacc[db][1] * inv), (half_t)(oacc[db][2] * inv), (half_t)(oacc[db][3] * inv)};
+            *reinterpret_cast<h4*>(orow + db * 16 + 4 * fq) = o;
+        }
+    }
+}
+
+template <int D, int TK>
+static int launch_attn_wide(const AttnParams& p, hipStream_t s) {
+    constexpr int LDS = 2 * 2 * TK * (D * 2 + 32);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_wide_kernel<D, TK>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    dim3 grid((p.Sq + 63) / 64, p.B * p.heads);
+    char nm[32];
+    snprintf(nm, sizeof(nm), "attn_wide_kernel<%d,%d>", D, TK);
+    lcm_prof_start(nm, s);
+    hipLaunchKernelGGL((attn_wide_kernel<D, TK>), grid, dim3(256), LDS, s, p);
+    lcm_prof_stop(s);
+    LCM_CHECK_LAUNCH("attention_wide");
+    return LCM_OK;
+}
+
 extern "C" int lcm_attention_f16(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* out,
                                  int ldo, int B, int heads, int Sq, int Sk, int d, float scale, int causal, void* stream) {
     LCM_REQUIRE(Q && K && V && out, "attention: null pointer");
@@ -272,6 +495,7 @@ extern "C" int lcm_attention_f16(const void* Q, int ldq, const void* K, int ldk,
         case 64: return launch_attn<64>(p, s);
         case 80: return launch_attn<80>(p, s);
         case 160: return launch_attn<160>(p, s);
-        default: lcm_set_error("attention: unsupported head_dim %d (40/64/80/160)", d); return LCM_EINVAL;
+        case 512: if (!causal) return launch_attn_wide<512, 32>(p, s);
+        default: lcm_set_error("attention: unsupported head_dim %d (40/64/80/160; 512 without causal mask)", d); return LCM_EINVAL;
     }
 }

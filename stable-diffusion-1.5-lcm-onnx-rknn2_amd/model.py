@@ -36,6 +36,9 @@ LN_FOLD = os.environ.get("LCM_LN_FOLD", "1") != "0"
 # the captured graph against 47.6 without -- a cross-stream edge costs more here than the ~10 us GEMM it takes off the chain.
 FORK_SHORTCUT = os.environ.get("LCM_FORK_SHORTCUT", "0") != "0"
 FUSE_GN_CONV = os.environ.get("LCM_FUSE_GN_CONV", "1") != "0"
+# AutoencoderKL mid-block attention (one head, d = 512) as ONE fused flash kernel behind one q|k|v GEMM; "0" = the round-1
+# GEMM -> softmax -> transpose -> GEMM form with its B x S x S score matrix in HBM (kept for comparison)
+VAE_FLASH_ATTN = os.environ.get("LCM_VAE_FLASH_ATTN", "1") != "0"
 FUSE_GN_MIN_BYTES = int(os.environ.get("LCM_FUSE_GN_MIN_BYTES", str(64 << 20)))
 
 
@@ -518,9 +521,14 @@ class VAEDecoderHip(_Net):
         a = "decoder.mid_block.attentions.0"
         self._put("attn.norm.g", sd[a + ".group_norm.weight"])
         self._put("attn.norm.b", sd[a + ".group_norm.bias"])
-        for n in ("to_q", "to_k", "to_v"):
-            self._put(f"attn.{n}.w", sd[f"{a}.{n}.weight"].reshape(boc[-1], boc[-1]))
-            self._put(f"attn.{n}.b", sd[f"{a}.{n}.bias"])
+        self.flash_attn = VAE_FLASH_ATTN and boc[-1] in (256, 512)
+        if self.flash_attn:
+            self._put("attn.qkv.w", torch.cat([sd[f"{a}.{n}.weight"].reshape(boc[-1], boc[-1]) for n in ("to_q", "to_k", "to_v")], 0))
+            self._put("attn.qkv.b", torch.cat([sd[f"{a}.{n}.bias"] for n in ("to_q", "to_k", "to_v")], 0))
+        else:
+            for n in ("to_q", "to_k", "to_v"):
+                self._put(f"attn.{n}.w", sd[f"{a}.{n}.weight"].reshape(boc[-1], boc[-1]))
+                self._put(f"attn.{n}.b", sd[f"{a}.{n}.bias"])
         self._put("attn.o.w", sd[a + ".to_out.0.weight"].reshape(boc[-1], boc[-1]))
         self._put("attn.o.b", sd[a + ".to_out.0.bias"])
         nb = len(boc)
@@ -541,6 +549,16 @@ class VAEDecoderHip(_Net):
         S, M = H * W, B * H * W
         hn = self.buf.get("gn", M, C)
         self.norm(x, w["attn.norm.g"], w["attn.norm.b"], hn, B, S, C, x_st=x_st, eps=1e-6, silu=False)
+        out = self.buf.get("res_out2", M, C)
+        out_st = self.stats("res_out2", M, C, S)
+        if self.flash_attn:
+            # one q|k|v GEMM, then the wide-head flash kernel (csrc/attention.hip attn_wide_kernel): no S x S scores in HBM
+            qkv = self.buf.get("attn_qkv", M, 3 * C)
+            ops.gemm(hn, w["attn.qkv.w"], qkv, bias=w["attn.qkv.b"], img_rows=S)
+            o = self.buf.get("attn_o", M, C)
+            ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], o, B, 1, S, S, C, ldq=3 * C, ldk=3 * C, ldv=3 * C, ldo=C)
+            ops.gemm(o, w["attn.o.w"], out, bias=w["attn.o.b"], res=x, stats=out_st, img_rows=S)
+            return out, out_st
         # The S x S product runs on the MFMA GEMM (N and K multiples of 64): S is padded to Sp with zero key rows / zero
         # V^T columns (allocated zero, never written), the softmax normalises over the S real keys and zeroes the padding.
         Sp = -(-S // 64) * 64
@@ -561,8 +579,6 @@ class VAEDecoderHip(_Net):
         ops.transpose(v, vt, S, C, ldi=C, ldo=Sp, batch=B, stride_in=S * C, stride_out=C * Sp)
         o = self.buf.get("attn_o", M, C)
         ops.gemm(sc, vt, o, M=S, N=C, K=Sp, lda=Sp, ldo=C, batch=B, strideA=S * Sp, strideW=C * Sp, strideO=S * C)
-        out = self.buf.get("res_out2", M, C)
-        out_st = self.stats("res_out2", M, C, S)
         ops.gemm(o, w["attn.o.w"], out, bias=w["attn.o.b"], res=x, stats=out_st, img_rows=S)
         return out, out_st
 
