@@ -164,10 +164,6 @@ int lcm_groupnorm_affine_f16(const void* x, int C1, const void* x2, int C2, cons
 /* launches of the LDS-halo conv with fewer workgroups than this use its pipelined variant (3-stage weight ring,
  * double-buffered halo) instead of the single-buffer high-occupancy one; default 768 */
 int lcm_set_halo_pipe_threshold(int wgs);
-/* 16x16-pixel (256-row) x 128-channel tile of the LDS-halo conv for unsplit launches on 16-wide patch grids: mode 0 off,
- * 1 in place of the 128-row tile when the launch still has >= min_tiles workgroups (default 1024), 2 wherever N % 128 == 0.
- * A launch parameter: never changes a bit (same K walk per output, canonical statistics slabs). */
-int lcm_set_halo_bm256(int mode, int min_tiles);
 /* 1 (default): stride-1 3x3 convolutions use the LDS-halo kernel; 0: the row-gather implicit GEMM everywhere */
 int lcm_set_conv_impl(int impl);
 

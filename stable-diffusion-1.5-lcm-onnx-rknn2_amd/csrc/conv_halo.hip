@@ -56,11 +56,8 @@ static inline int halo_slabs_per_image(int IH, int IW, int TW, bool ph) {
     return ((IH + rs - 1) / rs) * ((IW + TW - 1) / TW) * (ph ? 4 : 1);
 }
 
-// TH x TW = 16 x 16 (BM = 256, BN = 128): the large-grid form for the 128/256-channel AutoencoderKL layers -- every weight
-// slice streamed through LDS feeds twice the MFMAs (64 per wave per K-step) and a fragment read 0.375 instead of 0.5
-// MFMAs^-1; 128 accumulator VGPRs, 58 KB of LDS, two workgroups per CU.
 template <int TH, int TW, int BN, int XFORM, int PH>
-__global__ __launch_bounds__(256, TH * TW >= 256 ? 2 : 3) void conv_halo_kernel(HaloParams hp) {
+__global__ __launch_bounds__(256, 3) void conv_halo_kernel(HaloParams hp) {
     constexpr int NT = PH ? 4 : 9;
     constexpr int BM = TH * TW;
     constexpr int TM = BM / 32, TN = BN / 32, RW = BN / 32;
@@ -476,21 +473,6 @@ static void launch_halo(HaloParams& hp, hipStream_t s, int force) {     // force
     hp.tiles_x = ((PH ? hp.g.Win : hp.W) + TW - 1) / TW;
     hp.g.ntiles = hp.g.N / BN;
     dim3 grid(hp.g.mtiles * hp.g.ntiles, hp.g.splits, 1);
-    if constexpr (TH * TW >= 256) {      // 256-pixel tile: single-buffer kernel only (unsplit, unsegmented launches)
-        constexpr int smem = HROWS_PAD * 128 + BN * 128;
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<TH, TW, BN, XFORM, PH>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-            attr_set = true;
-        }
-        char nm[64];
-        snprintf(nm, sizeof(nm), "conv_halo_kernel<%d, %d, %d, %d, %d>", TH, TW, BN, XFORM, PH);
-        lcm_prof_start(nm, s);
-        hipLaunchKernelGGL((conv_halo_kernel<TH, TW, BN, XFORM, PH>), grid, dim3(256), smem, s, hp);
-        lcm_prof_stop(s);
-        return;
-    } else {
     if constexpr (!XFORM) if (hp.g.seg_parts > 1) {     // segmented accumulation: the pipelined kernel (2 workgroups per CU: room for `tot`)
         // (a kernel row of taps per step double-buffers its fragments in registers: with the second accumulator set that only
         // fits the 64-wide tile; wider tiles take one tap per step)
@@ -552,7 +534,6 @@ static void launch_halo(HaloParams& hp, hipStream_t s, int force) {     // force
     lcm_prof_start(nm, s);
     hipLaunchKernelGGL((conv_halo_kernel<TH, TW, BN, XFORM, PH>), grid, dim3(256), smem, s, hp);
     lcm_prof_stop(s);
-    }
 }
 
 // Tile + split candidates of the halo conv.  fixed_splits < 0: choose the split factor as well (the canonical
@@ -600,15 +581,6 @@ int lcm_canonical_splits_halo(int m_img, int N, int K, int IH, int IW, int W, in
     return lcm_split_policy(m_img, sp);
 }
 
-int g_halo_bm256 = 0;                    // see lcm_conv_halo_launch; set by lcm_set_halo_bm256
-long long g_halo_bm256_min_tiles = 1024;
-extern "C" int lcm_set_halo_bm256(int mode, int min_tiles) {
-    if (mode < 0 || mode > 2) { lcm_set_error("lcm_set_halo_bm256: mode %d (0 off, 1 in place of the 128-pixel tile, 2 always)", mode); return LCM_EINVAL; }
-    g_halo_bm256 = mode;
-    if (min_tiles > 0) g_halo_bm256_min_tiles = min_tiles;
-    return LCM_OK;
-}
-
 // returns 0 when launched, 1 when the shape is not handled here, < 0 on error
 int lcm_conv_halo_launch(HaloParams& hp, int B, hipStream_t s, int* slabs_per_image) {
     IgemmParams& p = hp.g;
@@ -628,14 +600,10 @@ int lcm_conv_halo_launch(HaloParams& hp, int B, hipStream_t s, int* slabs_per_im
     {   // autotuned plan for this shape, if any (kind 2; aux = (W << 1) | xform)
         int pbm, pbn, psp, pv;
         if (lcm_plan_get(2, p.M, p.N, p.K, (hp.W << 1) | (hp.gn_scale ? 1 : 0), &pbm, &pbn, &psp, &pv) && p.N % pbn == 0 &&
-            !(TW == 8 && pbm >= 128) && !(pbm == 256 && (pbn != 128 || ph || splits > 1))) {
+            !(TW == 8 && pbm == 128)) {
             bm = pbm; bn = pbn;
             force = (pv >= 1 && pv <= 3) ? pv : 0;
         }
-    }
-    if (g_halo_bm256 && TW == 16 && !ph && splits == 1 && p.N % 128 == 0 && (g_halo_bm256 == 2 || bm == 128) &&
-        (long long)B * ((IH + 15) / 16) * ((IW + 15) / 16) * (p.N / 128) >= g_halo_bm256_min_tiles) {
-        bm = 256; bn = 128;       // LCM_HALO_BM256: 1 = wherever the 128-pixel tile was chosen and the grid stays large, 2 = always
     }
     if (!bm) return 1;
     const int th = bm / TW;
@@ -666,10 +634,6 @@ int lcm_conv_halo_launch(HaloParams& hp, int B, hipStream_t s, int* slabs_per_im
         if (ph) launch_halo<TH_, TW_, BN_, 0, 1>(hp, s, force);                            \
         else if (xf) launch_halo<TH_, TW_, BN_, 1, 0>(hp, s, force);                       \
         else launch_halo<TH_, TW_, BN_, 0, 0>(hp, s, force);                               \
-    } else
-    if (th == 16 && TW == 16 && bn == 128 && !ph) {
-        if (xf) launch_halo<16, 16, 128, 1, 0>(hp, s, force);
-        else launch_halo<16, 16, 128, 0, 0>(hp, s, force);
     } else
     HALO_CASE(8, 16, 128) HALO_CASE(8, 16, 64) HALO_CASE(4, 16, 128) HALO_CASE(4, 16, 64)
     HALO_CASE(8, 8, 128) HALO_CASE(8, 8, 64) HALO_CASE(8, 16, 160) HALO_CASE(4, 16, 160) HALO_CASE(8, 8, 160) { return 1; }

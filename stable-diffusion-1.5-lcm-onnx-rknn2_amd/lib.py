@@ -70,7 +70,6 @@ _SIGS = {
     "lcm_set_conv_impl": [_i],
     "lcm_set_persist_n": [_i],
     "lcm_set_halo_pipe_threshold": [_i],
-    "lcm_set_halo_bm256": [_i, _i],
     "lcm_set_gn_fused_bytes": [_i64],
     "lcm_plan_set": [_i] * 9,
     "lcm_plan_clear": [],
@@ -107,8 +106,6 @@ def load():
     lib.lcm_groupnorm_ws_bytes.restype = _i64
     lib.lcm_groupnorm_ws_bytes.argtypes = [_i, _i, _i, _i]
     _install_plans(lib)
-    if os.environ.get("LCM_HALO_BM256"):            # experiment switch (csrc/conv_halo.hip, lcm_set_halo_bm256)
-        lib.lcm_set_halo_bm256(int(os.environ["LCM_HALO_BM256"]), int(os.environ.get("LCM_HALO_BM256_MIN_TILES", "0")))
     _lib = lib
     return lib
 

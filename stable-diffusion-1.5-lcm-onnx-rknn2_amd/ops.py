@@ -231,10 +231,6 @@ def set_halo_pipe_threshold(wgs):
     _lib.check(_lib.load().lcm_set_halo_pipe_threshold(int(wgs)), "lcm_set_halo_pipe_threshold")
 
 
-def set_halo_bm256(mode, min_tiles=0):
-    _lib.check(_lib.load().lcm_set_halo_bm256(int(mode), int(min_tiles)), "lcm_set_halo_bm256")
-
-
 def set_persist_n(on):
     _lib.check(_lib.load().lcm_set_persist_n(1 if on else 0), "lcm_set_persist_n")
 
