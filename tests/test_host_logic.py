@@ -143,6 +143,41 @@ def test_png_encoding_is_deterministic_and_lossless():
         del os.environ["LCM_PNG_ENCODER"]
 
 
+def test_png_parallel_deflate_is_one_valid_zlib_stream():
+    """Stripes deflated on several threads, concatenated behind one zlib header: the IDAT payload must inflate (header,
+    every segment boundary, the Adler-32 trailer) to exactly the filtered scanlines, for any stripe count and for heights
+    that do not divide evenly; the bytes are a function of the configuration, not of thread timing."""
+    import io, struct, zlib
+    from PIL import Image
+    from sdlcm_amd.backends.hip_worker import encode_png
+    rs = np.random.RandomState(1)
+    yy, xx = np.mgrid[0:360, 0:640]
+    img = (np.stack([xx // 3, yy // 2, (xx + yy) // 4], -1) + rs.randint(0, 6, size=(360, 640, 3))).astype(np.uint8)
+    old = os.environ.get("LCM_PNG_THREADS")
+    try:
+        files = {}
+        for thr in ("1", "2", "4", "5"):
+            os.environ["LCM_PNG_THREADS"] = thr
+            a = encode_png(img)
+            assert a == encode_png(img)
+            Image.open(io.BytesIO(a)).verify()
+            assert np.array_equal(np.asarray(Image.open(io.BytesIO(a))), img)
+            n = struct.unpack(">I", a[33:37])[0]
+            assert a[37:41] == b"IDAT"
+            raw = zlib.decompress(a[41:41 + n])                      # strict: checks the Adler-32 trailer
+            assert len(raw) == 360 * (1 + 640 * 3) and raw[0] == 2
+            files[thr] = a
+        assert files["1"] != files["4"]                              # really striped
+        os.environ["LCM_PNG_THREADS"] = "4"
+        small = rs.randint(0, 256, size=(64, 64, 3), dtype=np.uint8)  # under 128 scanlines: a single stripe
+        assert np.array_equal(np.asarray(Image.open(io.BytesIO(encode_png(small)))), small)
+    finally:
+        if old is None:
+            os.environ.pop("LCM_PNG_THREADS", None)
+        else:
+            os.environ["LCM_PNG_THREADS"] = old
+
+
 def test_hash_tokenizer_layout():
     from sdlcm_amd.clip import HashTokenizer, clip_param_spec
     from sdlcm_amd import weights
