@@ -17,6 +17,8 @@ import torch
 from . import ops
 from .config import TEXT_SEQ_LEN
 
+CLIP_GRAPH = os.environ.get("LCM_CLIP_GRAPH", "1") != "0"
+
 # OpenCLIP ViT-bigG/14 text tower (SDXL text_encoder_2, CLIPTextModelWithProjection): 32 layers, 1280 wide, exact GELU,
 # text_projection 1280 -> 1280 on the pooled (EOS) token.
 CLIP_BIGG = dict(vocab_size=49408, hidden_size=1280, intermediate_size=5120, num_hidden_layers=32, num_attention_heads=20,
@@ -103,6 +105,7 @@ class ClipTextHip:
         if self.has_proj:
             self.w["proj"] = dev(sd["text_projection.weight"])
         self._buf = {}
+        self._graphs, self._ids = {}, {}
 
     def _b(self, name, *shape):
         t = self._buf.get((name, shape))
@@ -119,6 +122,7 @@ class ClipTextHip:
         v = object.__new__(type(self))
         v.__dict__.update(self.__dict__)
         v._buf = {}
+        v._graphs, v._ids = {}, {}
         return v
 
     @torch.inference_mode()
@@ -127,15 +131,56 @@ class ClipTextHip:
         output="last": final_layer_norm(last layer)           -> fp16 [B, S, D]   (SD1.5: last_hidden_state)
         output="penultimate": hidden_states[-2], no final LN   -> fp16 [B, S, D]   (SDXL, both encoders)
         pooled=True additionally returns text_projection(final_layer_norm(last layer)[EOS token]) fp16 [B, P]
-        (CLIPTextModelWithProjection.text_embeds; EOS = position of the largest id, as transformers does for CLIP)."""
+        (CLIPTextModelWithProjection.text_embeds; EOS = position of the largest id, as transformers does for CLIP).
+
+        The SD1.5 form (output="last", no pooled vector) replays a hipGraph per (B, S): 86 launches through ctypes cost the
+        request's thread ~1 ms, one graph launch ~0.05 (LCM_CLIP_GRAPH=0: always eager).  Same kernels, same launch
+        parameters, same bits."""
         B, S = ids.shape
+        # (the legacy default stream cannot be captured: callers outside a lane's stream run eagerly)
+        if CLIP_GRAPH and output == "last" and not pooled and torch.cuda.current_stream(self.device) != torch.cuda.default_stream(self.device):
+            key = (B, S)
+            ids_d = self._ids.get(key)
+            if ids_d is None:
+                ids_d = self._ids[key] = torch.empty(B, S, dtype=torch.int32, device=self.device)
+            ids_d.copy_(ids.to(dtype=torch.int32), non_blocking=False)
+            g = self._graphs.get(key)
+            if g is None:
+                self._encode(ids_d, B, S, "last")                  # eager once: allocates the activation buffers
+                g = ops.Graph()
+                with g:
+                    self._encode(ids_d, B, S, "last")
+                self._graphs[key] = g
+            g.launch()
+            return self._b("fin", B * S, self.D).reshape(B, S, self.D).clone()     # the buffer belongs to the next call
+        ids_d = ids.to(device=self.device, dtype=torch.int32).contiguous()
+        hidden, fin = self._encode(ids_d, B, S, output, want_fin=pooled)
+        if output == "last":
+            hidden = hidden.clone()
+        if not pooled:
+            return hidden
+        if not self.has_proj:
+            raise ValueError("pooled output needs text_projection weights (CLIPTextModelWithProjection)")
+        D = self.D
+        eos = ids.to("cpu").long().argmax(dim=-1) + torch.arange(B) * S          # row of the EOS token per prompt
+        rows = fin.index_select(0, eos.to(self.device)).contiguous()               # gather = data movement only
+        P = self.w["proj"].shape[0]
+        te = torch.empty(B, P, dtype=torch.float16, device=self.device)
+        for b0 in range(0, B, 16):
+            nb = min(16, B - b0)
+            ops.linear_smallm(rows[b0:b0 + nb], self.w["proj"], te[b0:b0 + nb], nb, P, D)
+        return hidden, te
+
+    def _encode(self, ids_d, B, S, output, want_fin=False):
+        """The kernel sequence (what a graph captures).  -> (hidden [B,S,D], final-LN rows [M,D] or None); both in buffers
+        of this view."""
         D, F, H = self.D, self.F, self.heads
         M, d = B * S, D // H
         w = self.w
-        ids_d = ids.to(device=self.device, dtype=torch.int32).contiguous()
         x = self._b("x", M, D)
         ops.embed_tokens(ids_d, w["tok"], w["pos"], x, B, S, D)
         n, qkv, a, h = self._b("n", M, D), self._b("qkv", M, 3 * D), self._b("a", M, D), self._b("h", M, F)
+        pooled = want_fin
         pen = None
         last_needed = self.L if (output == "last" or pooled) else self.L - 1
         for i in range(last_needed):
@@ -155,22 +200,11 @@ class ClipTextHip:
             hidden = None
         fin = None
         if output == "last" or pooled:
-            fin = torch.empty(M, D, dtype=torch.float16, device=self.device)
+            fin = self._b("fin", M, D)
             ops.layernorm(x, w["fln.g"], w["fln.b"], fin, M, D, self.cfg["layer_norm_eps"])
             if output == "last":
                 hidden = fin.reshape(B, S, D)
-        if not pooled:
-            return hidden
-        if not self.has_proj:
-            raise ValueError("pooled output needs text_projection weights (CLIPTextModelWithProjection)")
-        eos = ids.to("cpu").long().argmax(dim=-1) + torch.arange(B) * S          # row of the EOS token per prompt
-        rows = fin.index_select(0, eos.to(self.device)).contiguous()               # gather = data movement only
-        P = self.w["proj"].shape[0]
-        te = torch.empty(B, P, dtype=torch.float16, device=self.device)
-        for b0 in range(0, B, 16):
-            nb = min(16, B - b0)
-            ops.linear_smallm(rows[b0:b0 + nb], self.w["proj"], te[b0:b0 + nb], nb, P, D)
-        return hidden, te
+        return hidden, fin
 
 
 class HashTokenizer:

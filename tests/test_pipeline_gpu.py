@@ -302,6 +302,35 @@ def test_clip_text_encoder_parity(B, act):
     assert e.max() < 2e-2 * max(1.0, np.abs(ref).max())
 
 
+def test_clip_graph_replay_equals_eager_and_follows_new_prompts():
+    """The SD1.5 prompt encoder replays a captured hipGraph per (B, 77): same bits as the eager kernel sequence, for the
+    prompt it was captured with and for later prompts (token ids live in a static device buffer), per batch size; the
+    returned tensor is the caller's own (a later encode must not overwrite it)."""
+    from sdlcm_amd import clip as clipmod
+    from sdlcm_amd.clip import CLIP_L, ClipTextHip, HashTokenizer, synthetic_clip
+    cfg = dict(CLIP_L, num_hidden_layers=4)
+    sd = synthetic_clip(cfg)
+    tok = HashTokenizer()
+    enc = ClipTextHip(sd, cfg, device="cuda:0")
+    prompts = [["a lighthouse at dusk"], ["two red kites over a beach"], ["a lighthouse at dusk", "", "oil painting of a cat"], [""]]
+    old = clipmod.CLIP_GRAPH
+    try:
+        clipmod.CLIP_GRAPH = False
+        eager = [enc.forward(tok(p)).clone() for p in prompts]
+        clipmod.CLIP_GRAPH = True
+        torch.cuda.synchronize()
+        with torch.cuda.stream(torch.cuda.Stream(device="cuda:0")):     # as a pipeline lane does; the default stream stays eager
+            first = enc.forward(tok(prompts[0]))
+            graphed = [first] + [enc.forward(tok(p)) for p in prompts[1:]]
+        torch.cuda.synchronize()
+    finally:
+        clipmod.CLIP_GRAPH = old
+    assert len(enc._graphs) == 2                                     # (1, 77) and (3, 77)
+    for e, g in zip(eager, graphed):
+        assert torch.equal(e, g)
+    assert not torch.equal(graphed[0], graphed[1])
+
+
 def test_sdxl_style_unet_parity():
     """The SDXL UNet family (row a16): 3 levels, no attention at level 0, transformer depth 1/2/3, 64-wide heads, Linear
     proj_in/out, "text_time" additional embedding, no time_cond_proj -- narrow widths, HIP executor vs oracle."""
