@@ -228,6 +228,22 @@ def test_batched_requests_match_single_requests(state, size, steps, B):
         assert np.array_equal(one["rgb"][0], batched["rgb"][i]), f"pixels of request {i} depend on the batch"
 
 
+@pytest.mark.parametrize("W,H,B", [(640, 360, 2), (512, 768, 2)])
+def test_batched_requests_match_single_requests_ui_sizes(state, W, H, B):
+    """The same contract at the reference UI's non-square stock sizes (lcm-sr-ui/src/utils/constants.js:6-15), whose launch
+    plans and per-image K partitions come from the shipped table (tools/extend_plans.py): 80x45 latents have odd UNet
+    levels (45 -> 23 -> 12 -> 6) and a ragged 16-wide patch grid."""
+    hip = state["hip"]
+    pe = _embeds(B, seed=22)
+    seeds = [1100 + i for i in range(B)]
+    batched = hip.generate(pe, seeds, W, H, 1, 1.0)
+    assert batched["rgb"].shape == (B, H, W, 3)
+    for i, s in enumerate(seeds):
+        one = hip.generate(pe[i:i + 1], [s], W, H, 1, 1.0)
+        assert np.array_equal(one["latents"][0], batched["latents"][i]), f"latents of request {i} depend on the batch"
+        assert np.array_equal(one["rgb"][0], batched["rgb"][i]), f"pixels of request {i} depend on the batch"
+
+
 def test_two_lanes_in_flight_match_solo_runs(state):
     """Two requests in flight at once on two lanes of one pipeline (own stream, scratch, graphs and split-K workspace;
     shared weights): every result is bit-identical to the same request run alone, repeatedly, with the lanes racing."""
