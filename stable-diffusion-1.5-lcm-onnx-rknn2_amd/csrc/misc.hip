@@ -108,8 +108,11 @@ __global__ __launch_bounds__(256) void conv_smalln_kernel(const half_t* __restri
                     for (int o = 0; o < 4; ++o) {
                         if (o < Cout) {
                             h8 w = *reinterpret_cast<const h8*>(ws + (o * 9 + tap) * Cin + cc * 8);
+                            // v_dot2_f32_f16: two exact fp16 products + fp32 accumulate per instruction (the scalar form
+                            // spends three VALU ops per product on conversions: 112 us for the 512^2 conv_out, VALU-bound)
 #pragma unroll
-                            for (int j = 0; j < 8; ++j) acc[o] += (float)v[j] * (float)w[j];
+                            for (int j = 0; j < 4; ++j)
+                                acc[o] = __builtin_amdgcn_fdot2((h2){v[2 * j], v[2 * j + 1]}, (h2){w[2 * j], w[2 * j + 1]}, acc[o], false);
                         }
                     }
                 }
@@ -134,6 +137,80 @@ __global__ __launch_bounds__(256) void conv_smalln_kernel(const half_t* __restri
     }
 }
 
+// Row-walking form for Cin == 8 * LPP (the AutoencoderKL conv_out: 128 -> 3 at full resolution): a lane group owns a run of
+// SEG pixels of one image row and slides the 3x3 window along it -- 3 new 16-byte loads per pixel instead of 9 -- with its
+// 8-channel slice of the Cout x 9 weights held in registers instead of re-read from LDS per pixel (27 ds_read_b128 each).
+// Same per-pixel arithmetic and order (taps 0..8, four v_dot2 each, then the lane-group reduction) as the kernel above.
+template <int LPP>
+__global__ __launch_bounds__(256) void conv_smalln_row_kernel(const half_t* __restrict__ in, const half_t* __restrict__ W,
+                                                              const half_t* __restrict__ bias, void* __restrict__ out,
+                                                              float* __restrict__ out_f32, int B, int H, int Wd, int Cout, int mode) {
+    constexpr int Cin = LPP * 8, SEG = 32, GPW = 256 / LPP;
+    const int sub = threadIdx.x % LPP, gl = threadIdx.x / LPP;
+    h8 wr[4][9];
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            wr[o][tap] = o < Cout ? *reinterpret_cast<const h8*>(W + (o * 9 + tap) * Cin + sub * 8) : z;
+        }
+    float bv[4];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) bv[o] = (bias && o < Cout) ? (float)bias[o] : 0.f;
+    const int segs_x = (Wd + SEG - 1) / SEG;
+    const long long nseg = (long long)B * H * segs_x;
+    for (long long sg = (long long)blockIdx.x * GPW + gl; sg < nseg; sg += (long long)gridDim.x * GPW) {
+        const int sx = (int)(sg % segs_x), y = (int)((sg / segs_x) % H), b = (int)(sg / ((long long)segs_x * H));
+        const int x0 = sx * SEG, x1 = min(Wd, x0 + SEG);
+        const half_t* base = in + ((long long)b * H * Wd) * Cin + sub * 8;
+        auto load_col = [&](int x, h8 (&c)[3]) {
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const int iy = y + dy - 1;
+                h8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                c[dy] = (x >= 0 && x < Wd && iy >= 0 && iy < H) ? *reinterpret_cast<const h8*>(base + ((long long)iy * Wd + x) * Cin) : z;
+            }
+        };
+        h8 c0[3], c1[3], c2[3];
+        load_col(x0 - 1, c0);
+        load_col(x0, c1);
+        for (int x = x0; x < x1; ++x) {
+            load_col(x + 1, c2);
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int dy = tap / 3, dx = tap % 3;
+                const h8 v = dx == 0 ? c0[dy] : dx == 1 ? c1[dy] : c2[dy];
+#pragma unroll
+                for (int o = 0; o < 4; ++o)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[o] = __builtin_amdgcn_fdot2((h2){v[2 * j], v[2 * j + 1]}, (h2){wr[o][tap][2 * j], wr[o][tap][2 * j + 1]}, acc[o], false);
+            }
+#pragma unroll
+            for (int o = 0; o < 4; ++o)
+#pragma unroll
+                for (int off = LPP / 2; off > 0; off >>= 1) acc[o] += __shfl_xor(acc[o], off, 64);
+            if (sub == 0) {
+                const long long pix = ((long long)b * H + y) * Wd + x;
+                for (int o = 0; o < Cout; ++o) {
+                    const float yv = acc[o] + bv[o];
+                    if (out_f32) out_f32[pix * Cout + o] = yv;
+                    if (mode == 0) {
+                        reinterpret_cast<float*>(out)[pix * Cout + o] = yv;
+                    } else {
+                        const float u = fminf(fmaxf(yv * 0.5f + 0.5f, 0.f), 1.f);
+                        reinterpret_cast<unsigned char*>(out)[pix * Cout + o] = (unsigned char)rintf(u * 255.f);
+                    }
+                }
+            }
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) { c0[dy] = c1[dy]; c1[dy] = c2[dy]; }
+        }
+    }
+}
+
 extern "C" int lcm_conv3x3_smalln(const void* in, const void* W, const void* bias, void* out, void* out_f32, int B,
                                   int H, int Wd, int Cin, int Cout, int mode, void* stream) {
     LCM_REQUIRE(in && W && out, "conv_smalln: null pointer");
@@ -151,7 +228,17 @@ extern "C" int lcm_conv3x3_smalln(const void* in, const void* W, const void* bia
                            (const half_t*)in, (const half_t*)W, (const half_t*)bias, out, (float*)out_f32, B, H,  \
                            Wd, Cin, Cout, mode);                                                                  \
     } while (0)
-    if (ncc <= 16) LAUNCH_SN(16); else if (ncc <= 32) LAUNCH_SN(32); else LAUNCH_SN(64);
+#define LAUNCH_ROW(L)                                                                                             \
+    do {                                                                                                          \
+        const long long nseg = (long long)B * H * ((Wd + 31) / 32), wg = (nseg + (256 / L) - 1) / (256 / L);      \
+        hipLaunchKernelGGL((conv_smalln_row_kernel<L>), dim3((int)(wg < 16384 ? wg : 16384)), dim3(256), 0, s,    \
+                           (const half_t*)in, (const half_t*)W, (const half_t*)bias, out, (float*)out_f32, B, H,  \
+                           Wd, Cout, mode);                                                                       \
+    } while (0)
+    if (ncc == 16) LAUNCH_ROW(16);
+    else if (ncc == 32) LAUNCH_ROW(32);
+    else if (ncc <= 16) LAUNCH_SN(16); else if (ncc <= 32) LAUNCH_SN(32); else LAUNCH_SN(64);
+#undef LAUNCH_ROW
 #undef LAUNCH_SN
     LCM_CHECK_LAUNCH("conv_smalln");
     return LCM_OK;

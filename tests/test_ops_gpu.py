@@ -525,9 +525,12 @@ def test_conv_c4(pre):
     close(from_nhwc(out, B, H, W), ref, what="conv_c4")
 
 
-@pytest.mark.parametrize("Cin,Cout,mode", [(320, 4, 0), (128, 3, 1), (256, 3, 1)])
-def test_conv_smalln(Cin, Cout, mode):
-    B, H, W = 2, 20, 12
+@pytest.mark.parametrize("Cin,Cout,mode,shape", [(320, 4, 0, (2, 20, 12)), (128, 3, 1, (2, 20, 12)), (256, 3, 1, (2, 20, 12)),
+                                                 (128, 3, 1, (1, 9, 72)), (128, 4, 0, (3, 5, 33)), (64, 3, 1, (1, 8, 40))])
+def test_conv_smalln(Cin, Cout, mode, shape):
+    """conv_out (<= 4 output channels).  Cin 128 / 256 take the row-walking kernel (sliding 3x3 window along runs of 32 pixels:
+    widths 12, 33, 72 give a short run, a 1-pixel tail and a ragged third run), the others the per-pixel kernel."""
+    B, H, W = shape
     x = rnd(B, Cin, H, W, seed=1)
     w = rnd(Cout, Cin, 3, 3, seed=2, scale=(9 * Cin) ** -0.5)
     b = rnd(Cout, seed=3, scale=0.1)
