@@ -14,8 +14,11 @@ __global__ __launch_bounds__(256) void conv_c4_kernel(const float* __restrict__ 
                                                       const half_t* __restrict__ W, const half_t* __restrict__ bias,
                                                       half_t* __restrict__ out, int B, int H, int Wd, int Cout) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    half_t* ws = reinterpret_cast<half_t*>(smem);           // [Cout][36]
-    for (int i = threadIdx.x; i < Cout * 36; i += 256) ws[i] = W[i];
+    half_t* ws = reinterpret_cast<half_t*>(smem);           // [Cout][40]: 36 weights + 4 pad, rows 16-byte aligned
+    for (int i = threadIdx.x; i < Cout * 40; i += 256) {
+        const int co = i / 40, k = i - co * 40;
+        ws[i] = k < 36 ? W[co * 36 + k] : (half_t)0.f;
+    }
     __syncthreads();
     const int ng = Cout >> 3;
     const long long total = (long long)B * H * Wd * ng;
@@ -51,9 +54,14 @@ __global__ __launch_bounds__(256) void conv_c4_kernel(const float* __restrict__ 
         for (int j = 0; j < 8; ++j) {
             const int co = g * 8 + j;
             float acc = bias ? (float)bias[co] : 0.f;
-            const half_t* wr = ws + co * 36;
+            const half_t* wr = ws + co * 40;            // five 16-byte LDS reads per output channel (were 36 two-byte ones)
 #pragma unroll
-            for (int k = 0; k < 36; ++k) acc += v[k] * (float)wr[k];
+            for (int k8 = 0; k8 < 5; ++k8) {
+                const h8 w8 = *reinterpret_cast<const h8*>(wr + k8 * 8);
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (k8 * 8 + k < 36) acc += v[k8 * 8 + k] * (float)w8[k];
+            }
             o[j] = (half_t)acc;
         }
         *reinterpret_cast<h8*>(out + pix * Cout + g * 8) = o;
@@ -64,11 +72,11 @@ extern "C" int lcm_conv3x3_c4_f32in(const void* in, const void* pre_w, const voi
                                     const void* W, const void* bias, void* out, int B, int H, int Wd, int Cout,
                                     void* stream) {
     LCM_REQUIRE(in && W && out, "conv_c4: null pointer");
-    LCM_REQUIRE(B > 0 && H > 0 && Wd > 0 && Cout % 8 == 0 && Cout <= 1024, "conv_c4: bad shape");
+    LCM_REQUIRE(B > 0 && H > 0 && Wd > 0 && Cout % 8 == 0 && Cout * 80 <= 64 * 1024, "conv_c4: bad shape (Cout %d)", Cout);
     LCM_REQUIRE((pre_w == nullptr) == (pre_b == nullptr), "conv_c4: pre_w/pre_b must come together");
     const long long total = (long long)B * H * Wd * (Cout / 8);
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(conv_c4_kernel, dim3(grid), dim3(256), Cout * 36 * 2, (hipStream_t)stream, (const float*)in,
+    hipLaunchKernelGGL(conv_c4_kernel, dim3(grid), dim3(256), Cout * 40 * 2, (hipStream_t)stream, (const float*)in,
                        (const float*)pre_w, (const float*)pre_b, in_scale, (const half_t*)W, (const half_t*)bias,
                        (half_t*)out, B, H, Wd, Cout);
     LCM_CHECK_LAUNCH("conv_c4");
