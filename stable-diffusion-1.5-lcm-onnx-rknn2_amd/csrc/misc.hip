@@ -14,13 +14,18 @@ __global__ __launch_bounds__(256) void conv_c4_kernel(const float* __restrict__ 
                                                       const half_t* __restrict__ W, const half_t* __restrict__ bias,
                                                       half_t* __restrict__ out, int B, int H, int Wd, int Cout) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    half_t* ws = reinterpret_cast<half_t*>(smem);           // [Cout][40]: 36 weights + 4 pad, rows 16-byte aligned
-    for (int i = threadIdx.x; i < Cout * 40; i += 256) {
-        const int co = i / 40, k = i - co * 40;
-        ws[i] = k < 36 ? W[co * 36 + k] : (half_t)0.f;
+    // weights in LDS as 16-byte chunks [k8 = 0..4][j = 0..7][g]: chunk (k8, j, g) = W[g*8 + j][8*k8 .. 8*k8+7] (zero past 36).
+    // A wave's lanes are consecutive g of one pixel, so each ds_read_b128 of a wave walks consecutive chunks: conflict-free
+    // (rows of 36 or 40 halfs per output channel put the lanes 8 rows apart -- 8- to 16-way bank conflicts).
+    half_t* ws = reinterpret_cast<half_t*>(smem);
+    const int ng = Cout >> 3;
+    for (int i = threadIdx.x; i < Cout * 10; i += 256) {    // 8-byte pieces of the [Cout][36] rows (coalesced), scattered into place
+        const int co = i / 10, q = i - co * 10;             // q = 4-element piece of the row; piece 9 is the zero pad
+        h4 v = {0, 0, 0, 0};
+        if (q < 9) v = *reinterpret_cast<const h4*>(W + co * 36 + q * 4);
+        *reinterpret_cast<h4*>(ws + (((q >> 1) * 8 + (co & 7)) * ng + (co >> 3)) * 8 + (q & 1) * 4) = v;
     }
     __syncthreads();
-    const int ng = Cout >> 3;
     const long long total = (long long)B * H * Wd * ng;
     const long long plane = (long long)H * Wd;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
@@ -54,10 +59,9 @@ __global__ __launch_bounds__(256) void conv_c4_kernel(const float* __restrict__ 
         for (int j = 0; j < 8; ++j) {
             const int co = g * 8 + j;
             float acc = bias ? (float)bias[co] : 0.f;
-            const half_t* wr = ws + co * 40;            // five 16-byte LDS reads per output channel (were 36 two-byte ones)
 #pragma unroll
-            for (int k8 = 0; k8 < 5; ++k8) {
-                const h8 w8 = *reinterpret_cast<const h8*>(wr + k8 * 8);
+            for (int k8 = 0; k8 < 5; ++k8) {                // five 16-byte LDS reads per output channel (were 36 two-byte ones)
+                const h8 w8 = *reinterpret_cast<const h8*>(ws + ((k8 * 8 + j) * ng + g) * 8);
 #pragma unroll
                 for (int k = 0; k < 8; ++k)
                     if (k8 * 8 + k < 36) acc += v[k8 * 8 + k] * (float)w8[k];
@@ -75,7 +79,8 @@ extern "C" int lcm_conv3x3_c4_f32in(const void* in, const void* pre_w, const voi
     LCM_REQUIRE(B > 0 && H > 0 && Wd > 0 && Cout % 8 == 0 && Cout * 80 <= 64 * 1024, "conv_c4: bad shape (Cout %d)", Cout);
     LCM_REQUIRE((pre_w == nullptr) == (pre_b == nullptr), "conv_c4: pre_w/pre_b must come together");
     const long long total = (long long)B * H * Wd * (Cout / 8);
-    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    // at most ~4 workgroups per CU: the weight staging of a workgroup is amortised over several pixels per thread
+    const int grid = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
     hipLaunchKernelGGL(conv_c4_kernel, dim3(grid), dim3(256), Cout * 40 * 2, (hipStream_t)stream, (const float*)in,
                        (const float*)pre_w, (const float*)pre_b, in_scale, (const half_t*)W, (const half_t*)bias,
                        (half_t*)out, B, H, Wd, Cout);

@@ -4,7 +4,7 @@
   pass_breakdown.py <rocprof output dir> [rows]
 
 One pass = one hipGraph replay of the sampler = the kernels between two consecutive final VAE convolutions
-(conv_smalln<16>, the RGB8 epilogue).  Run it on a trace of `bench.py --no-roofline --no-extra --no-cpu-baseline`:
+(conv_smalln[_row]<16>, the RGB8 epilogue).  Run it on a trace of `bench.py --no-roofline --no-extra --no-cpu-baseline`:
 the roofline leg replays the dominant kernel back to back outside any pass and would otherwise land inside the window
 (round 1's breakdowns were 2x off for that kernel).  The window is taken from the timed region (the last replays) and
 is checked: every one of the last three windows must hold the same number of kernels."""
@@ -12,7 +12,7 @@ import collections, csv, glob, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 ks = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows)
-ends = [i for i, k in enumerate(ks) if "conv_smalln_kernelILi16" in k[2] or "conv_smalln_kernel<16>" in k[2]]
+ends = [i for i, k in enumerate(ks) if "conv_smalln_" in k[2] and ("kernelILi16" in k[2] or "kernel<16>" in k[2])]
 assert len(ends) >= 5, "need at least 4 passes in the trace"
 wins = [(ends[-k - 1] + 1, ends[-k] + 1) for k in (1, 2, 3)]
 sizes = [b - a for a, b in wins]
