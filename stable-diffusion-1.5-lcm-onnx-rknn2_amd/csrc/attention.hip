@@ -167,23 +167,21 @@ __global__ __launch_bounds__(64 * WAVES) void attn_kernel(AttnParams p) {
                 for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
             m_run = m_new;
         }
+        // P and O^T += V^T P^T per 32-key half: the four MFMAs of half 0 run in the matrix pipe while the VALU computes the
+        // exponentials of half 1 (with one wave per SIMD -- batch 1 -- nothing else overlaps the two).  Every accumulator
+        // still sees (kb0,s0), (kb0,s1), (kb1,s0), (kb1,s1) in that order: same bits as the unsplit form.
         float psum = 0.f;
-        h8 pf[2][2];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < 2; ++kb) {
+            h8 pf[2];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float pv = __builtin_amdgcn_exp2f(sacc[kb][r] * p.sc - m_run);
                 if (!C::ONES) psum += pv;
-                pf[kb][r >> 3][r & 7] = (half_t)pv;
+                pf[r >> 3][r & 7] = (half_t)pv;
             }
-        if (!C::ONES) l_run += psum;
-
-        // ---- O^T += V^T P^T ----
 #pragma unroll
-        for (int db = 0; db < C::DV / 32; ++db) {
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int db = 0; db < C::DV / 32; ++db)
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     const char* base = Vs + v_addr + (kb * 32 + 16 * s) * C::VS + db * 64;
@@ -192,9 +190,10 @@ __global__ __launch_bounds__(64 * WAVES) void attn_kernel(AttnParams p) {
                         (s4 __attribute__((address_space(3)))*)(base + 8 * C::VS));
                     h4 lo_h = __builtin_bit_cast(h4, lo), hi_h = __builtin_bit_cast(h4, hi);
                     h8 vf = {lo_h[0], lo_h[1], lo_h[2], lo_h[3], hi_h[0], hi_h[1], hi_h[2], hi_h[3]};
-                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kb][s], oacc[db], 0, 0, 0);
+                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[s], oacc[db], 0, 0, 0);
                 }
         }
+        if (!C::ONES) l_run += psum;
     };
     const bool ragged = (p.Sk & 63) != 0;
     for (int t = 0; t < ntiles; ++t) {
