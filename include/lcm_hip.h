@@ -216,9 +216,15 @@ int lcm_layernorm_f16(const void* x, const void* gamma, const void* beta, void* 
  */
 int lcm_attention_f16(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* out, int ldo,
                       int B, int heads, int Sq, int Sk, int d, float scale, int causal, void* stream);
-/* query rows per attention workgroup: 0 / 4 = 128 (default), 2 = 64 (twice the workgroups; measured slower at batch 1:
- * every workgroup re-stages all K/V tiles).  Bit-neutral. */
+/* query rows per attention workgroup: 0 = by grid size, 4 = 128, 8 = 256 (streaming kernel only), 2 = 64 (register-staged
+ * kernel only; measured slower at batch 1: every workgroup re-stages all K/V tiles).  Bit-neutral within a kernel. */
 int lcm_set_attention_waves(int waves);
+/* Which kernel serves the long non-causal sequences (Sk >= 128, d in {40, 64, 80}: the UNet's self-attention at the 64^2 / 32^2
+ * levels, SDXL): 1 (default) = the streaming kernel (K/V tiles by LDS-DMA into a double buffer, Q pre-scaled, running max
+ * carried in the padding k-slots of the QK^T MFMA for d = 40, deferred rescale), 0 = the register-staged kernel that serves
+ * everything else.  Which kernel runs is a function of (d, Sk, causal) only -- never of B -- so a request's bits do not depend
+ * on the batch; the two kernels differ in rounding (Q scaling in fp16, deferred max). */
+int lcm_set_attention_impl(int impl);
 /* causal != 0: keys after the query are masked (CLIPTextModel's causal attention mask, transformers; the text
  * encoder call of the pipeline, twin backends/rknnlcm.py:266-367). */
 

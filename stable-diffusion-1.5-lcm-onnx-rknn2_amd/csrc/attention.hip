@@ -225,7 +225,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_kernel(AttnParams p) {
 
 static int g_attn_waves = 0;      // 0: by grid size; 2 / 4: forced (tests)
 extern "C" int lcm_set_attention_waves(int waves) {
-    if (waves != 0 && waves != 2 && waves != 4) { lcm_set_error("attention_waves: %d", waves); return LCM_EINVAL; }
+    if (waves != 0 && waves != 2 && waves != 4 && waves != 8) { lcm_set_error("attention_waves: %d", waves); return LCM_EINVAL; }
     g_attn_waves = waves;
     return LCM_OK;
 }
@@ -258,6 +258,353 @@ static int launch_attn(const AttnParams& p, hipStream_t s) {
     return g_attn_waves == 2 ? launch_attn_w<D, 2>(p, s) : launch_attn_w<D, 4>(p, s);
 }
 
+
+template <int N>
+__device__ __forceinline__ void attn_wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+template <int... I, class F>
+__device__ __forceinline__ void attn_static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void attn_static_for(F&& f) {
+    attn_static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
+// Transposed fragment read as inline asm: through the builtin the compiler cannot tell the read from the LDS-DMA writes of the
+// next tile in flight (other buffer) and drains the DMA (s_waitcnt vmcnt(0)) in front of it in every tile.  The caller waits
+// with attn2_wait_lgkm (which names the destination registers) before the first use.
+template <int OFF>
+__device__ __forceinline__ s4 attn2_tr(int addr) {
+    s4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+template <int N>
+__device__ __forceinline__ void attn2_wait_lgkm(s4 (&r)[N]) {
+    static_assert(N == 8 || N == 12, "4 reads per d-block");
+    if constexpr (N == 8)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]));
+    else
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]),
+                     "+v"(r[8]), "+v"(r[9]), "+v"(r[10]), "+v"(r[11]));
+}
+__device__ __forceinline__ int xcd_remap_attn(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+// ------------------------------------------------------------------------------------------------
+// attn2: the self-attention kernel of the long sequences (non-causal, Sk >= 128, d in {40, 64, 80}: UNet levels 0 / 1 at
+// 512^2 and up, SDXL).  Same MFMA formulation as attn_kernel (swapped QK^T on 32x32x16, S^T accumulators are the B operand
+// of O^T += V^T P^T, V^T fragments by ds_read_b64_tr_b16) with the work around the MFMAs rebuilt:
+//   * K/V tiles (64 keys) arrive by LDS-DMA into a DOUBLE buffer: tile t+1 is in flight during all of tile t, ONE barrier per
+//     tile, no staging registers, no ds_write pass.  The LDS image is dense ([key][d], 2d-byte rows: a 1 KiB DMA piece is 64
+//     consecutive 16-byte chunks); bank conflicts are handled on the SOURCE side (the lane that fills chunk position p of
+//     row r fetches chunk unswz(p, r)): none needed for d = 40 (80-byte rows: 16 consecutive rows hit 16 distinct 16-byte
+//     slots), a GF(2) XOR for d = 64, a rotation for d = 80 (tools/lds_bank_model.py).
+//   * Q is scaled by scale*log2(e) once, in registers (fp16), so P = exp2(S - m) needs no multiply.
+//   * d = 40 (MFOLD): the 8 padding k-slots of the third QK^T step carry the running max: the lanes of those slots read a
+//     constant K fragment (1, 1, 0, ...) and hold (hi, lo) = fp16 split of -m in their Q fragment, so the MFMA itself
+//     produces S - m and the 32 subtractions per tile disappear from the VALU (the softmax VALU, not the MFMA, bounds this
+//     kernel).  The running max only moves when a score exceeds it by more than 2^THR (deferred rescale): the rescale
+//     branch (O *= alpha, S -= delta, new (hi, lo)) is rare after the first tiles.
+//   * row sums ride in the padding row d of O^T (V^T row d = 1): lanes whose V^T rows are padding read constant cells
+//     ((1,0,0,0) or zeros) instead of tile bytes.  The cells are replicated at every immediate offset the reads use, so all
+//     fragment reads are `base VGPR + immediate` with loop-invariant bases (the tile loop is unrolled by the two buffers).
+//   * 8-wave workgroups (256 query rows) for batched launches halve the K/V staging per query; 4-wave workgroups (128 rows)
+//     when that would leave CUs idle.  A query row's arithmetic is the same either way (one wave = 32 rows).
+//   * workgroup -> (image*head, query block) through the XCD remap: the query blocks of one head run on one XCD and share its
+//     K/V in that XCD's L2.
+// ------------------------------------------------------------------------------------------------
+template <int D>
+struct Attn2Cfg {
+    static constexpr int NCH = D / 8, ROWB = D * 2;
+    static constexpr int DK = (D + 15) / 16 * 16, NKS = DK / 16;
+    static constexpr int DV = (D + 31) / 32 * 32, NDB = DV / 32;
+    static constexpr bool MFOLD = (DK - D) >= 8;        // the last k-step's upper half is padding: it carries -m
+    static constexpr bool ONES = DV > D;                 // padding row D of O^T accumulates the row sums
+    static constexpr int TILE = 64 * ROWB, BUFB = 2 * TILE;
+    static constexpr int CELLS = 2 * BUFB;               // constant cells: V cell at CELLS + buf*BUFB + 8i*ROWB (i < 8), K cell 16 B behind
+    static constexpr int LDS_BYTES = (MFOLD || ONES) ? CELLS + BUFB + 56 * ROWB + 32 : CELLS;
+    static constexpr int ONES_DB = D / 32, ONES_REG = 4 * ((D % 32) >> 3) + ((D % 32) & 3);
+    static_assert(!ONES || ((D % 32) % 8 < 4), "row-sum row must land in lanes 0-31");
+    // chunk position of chunk c in row r of the dense LDS image (source-side swizzle), and its inverse
+    static __device__ __forceinline__ int pos(int c, int r) {
+        if constexpr (D == 64) return c ^ (((r >> 1) & 1) | (((r >> 2) & 1) << 1) | ((((r >> 1) ^ (r >> 3)) & 1) << 2));
+        else if constexpr (D == 80) { const int v = c + 3 * ((r >> 3) & 1); return v >= NCH ? v - NCH : v; }
+        else return c;
+    }
+    static __device__ __forceinline__ int unpos(int p, int r) {
+        if constexpr (D == 64) return pos(p, r);
+        else if constexpr (D == 80) { const int v = p - 3 * ((r >> 3) & 1); return v < 0 ? v + NCH : v; }
+        else return p;
+    }
+};
+
+template <int OFF>
+__device__ __forceinline__ h8 attn2_read_b128(int addr) {
+    return *reinterpret_cast<const __attribute__((address_space(3))) h8*>((size_t)(unsigned)(addr + OFF));
+}
+
+template <int D, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 2 : 1) void attn2_kernel(AttnParams p, int nqb) {
+    using C = Attn2Cfg<D>;
+    constexpr int NP = (2 * C::NCH + WAVES - 1) / WAVES;        // DMA pieces per wave per tile
+    constexpr float THR = 8.0f;                                   // deferred rescale: P <= 2^THR (fp16: no precision cost)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int v = xcd_remap_attn(blockIdx.x, gridDim.x);
+    const int bh = v / nqb, qb = v - bh * nqb;
+    const int b = bh / p.heads, head = bh - b * p.heads;
+    const int qrow = qb * (32 * WAVES) + wave * 32 + l31;
+
+    const half_t* Qb = p.Q + (long long)b * p.Sq * p.ldq + head * D;
+    const half_t* Kb = p.K + (long long)b * p.Sk * p.ldk + head * D;
+    const half_t* Vb = p.V + (long long)b * p.Sk * p.ldv + head * D;
+
+    // ---- constant cells ----
+    if constexpr (C::MFOLD || C::ONES) {
+        for (int i = C::CELLS + tid * 16; i < C::LDS_BYTES; i += 64 * WAVES * 16) *reinterpret_cast<f4*>(smem + i) = (f4){0.f, 0.f, 0.f, 0.f};
+        __syncthreads();
+        if (tid < 16) {
+            char* cell = smem + C::CELLS + (tid >> 3) * C::BUFB + (tid & 7) * 8 * C::ROWB;
+            if (C::ONES) *reinterpret_cast<half_t*>(cell) = (half_t)1.0f;                         // (1,0,0,0 | 0,0,0,0)
+            if (C::MFOLD && (tid & 3) == 0) { reinterpret_cast<half_t*>(cell + 16)[0] = (half_t)1.0f;   // (1,1,0,...): kb = (tid&7)>>2
+                                              reinterpret_cast<half_t*>(cell + 16)[1] = (half_t)1.0f; }
+        }
+    }
+
+    // ---- DMA pieces of this wave: piece i < NCH = chunks [64i, 64i+64) of the K tile, else of the V tile ----
+    int pc_off[NP], pc_row[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const int i = wave + j * WAVES;
+        const int pi = i >= C::NCH ? i - C::NCH : i;
+        const int pidx = pi * 64 + lane;
+        const int row = pidx / C::NCH, ps = pidx - row * C::NCH;
+        pc_row[j] = row;
+        pc_off[j] = row * (i >= C::NCH ? p.ldv : p.ldk) + C::unpos(ps, row) * 8;
+    }
+    const int ntiles = (p.Sk + 63) >> 6;
+    auto issue_tile = [&](int t, int buf) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int i = wave + j * WAVES;
+            if (i < 2 * C::NCH) {
+                const bool isv = i >= C::NCH;
+                const int ld = isv ? p.ldv : p.ldk;
+                int off = pc_off[j];
+                const int last = p.Sk - 1 - t * 64;                       // rows past Sk re-read the last real row (finite; masked)
+                if (pc_row[j] > last) off -= (pc_row[j] - last) * ld;
+                const half_t* src = (isv ? Vb : Kb) + (long long)t * 64 * ld + off;
+                char* dst = smem + buf * C::BUFB + (isv ? C::TILE + (i - C::NCH) * 1024 : i * 1024);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            }
+        }
+    };
+    issue_tile(0, 0);
+
+    // ---- Q fragments (B operand), scaled by scale*log2(e): lane holds Q[qrow][16ks + 8hh + j] ----
+    h8 qf[C::NKS];
+#pragma unroll
+    for (int ks = 0; ks < C::NKS; ++ks) {
+        const int dc = 16 * ks + 8 * hh;
+        h8 x = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (qrow < p.Sq && dc < D) x = *reinterpret_cast<const h8*>(Qb + (long long)qrow * p.ldq + dc);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = (half_t)((float)x[j] * p.sc);
+        qf[ks] = x;
+    }
+
+    // ---- per-lane fragment addresses (loop invariant; immediates select buffer / key block) ----
+    int kaddr[C::NKS];
+#pragma unroll
+    for (int ks = 0; ks < C::NKS; ++ks) {
+        const int c = 2 * ks + hh;
+        kaddr[ks] = c < C::NCH ? l31 * C::ROWB + C::pos(c, l31) * 16 : C::CELLS + 16;
+    }
+    const int vq = (lane & 15) >> 2, vp = lane & 3, vg1 = (lane >> 4) & 1;
+    int vaddr[C::NDB][2];
+#pragma unroll
+    for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+        for (int hi = 0; hi < 2; ++hi) {
+            const int d = db * 32 + 16 * vg1 + 4 * vp;
+            const int key = 8 * hi + 4 * hh + vq;
+            vaddr[db][hi] = d < D ? C::TILE + key * C::ROWB + C::pos(d >> 3, key) * 16 + (d & 7) * 2
+                                  : (d == D ? C::CELLS : C::CELLS + 8) + 8 * hi * C::ROWB;
+        }
+
+    f16v oacc[C::NDB];
+#pragma unroll
+    for (int i = 0; i < C::NDB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+    float m_run = 0.f, l_run = 0.f;
+
+    auto tile = [&](int t, auto buf_tag) {
+        constexpr int BUF = decltype(buf_tag)::value;
+        attn_wait_vmcnt<0>();                 // this wave's pieces of tile t have landed
+        __builtin_amdgcn_s_barrier();         // everyone's have; everyone is done with the other buffer (tile t-1)
+        if (t + 1 < ntiles) issue_tile(t + 1, BUF ^ 1);
+
+        // ---- S^T = K Q^T (MFOLD: minus the running max) ----
+        f16v sacc[2];
+        attn_static_for<2>([&](auto kb_) {
+            constexpr int kb = decltype(kb_)::value;
+            const f16v zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            attn_static_for<C::NKS>([&](auto ks_) {
+                constexpr int ks = decltype(ks_)::value;
+                const h8 kf = attn2_read_b128<BUF * C::BUFB + kb * 32 * C::ROWB>(kaddr[ks]);
+                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], ks == 0 ? zero : sacc[kb], 0, 0, 0);
+            });
+        });
+        if (t == ntiles - 1 && (p.Sk & 63)) {          // ragged last tile
+            int lim = p.Sk - t * 64 - 4 * hh;             // (opaque: keeps the 32 compare masks out of loop-invariant SGPRs)
+            asm volatile("" : "+v"(lim));
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (kb * 32 + (r & 3) + 8 * (r >> 2) >= lim) sacc[kb][r] = -1.0e30f;
+        }
+        float mt = sacc[0][0];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mt = fmaxf(mt, sacc[kb][r]);
+        {   // join the two lane halves of a query column
+            // inline asm: with the builtin the compiler folds the max of the two swap results into one of them (only one lane
+            // half then sees the other's maximum).  s_nop 1 = the 2 wait states between a VALU write and v_permlane*_swap.
+            float ma = mt, mb = mt;
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(ma), "+v"(mb));
+            mt = fmaxf(ma, mb);
+        }
+        const float grow = C::MFOLD ? mt : mt - m_run;          // how far this tile's max exceeds the running one
+        float sub = C::MFOLD ? 0.f : m_run;
+        if (t == 0 || __any(grow > THR)) {
+            const float delta = t == 0 ? grow : fmaxf(grow, 0.f);
+            if (t != 0) {
+                const float alpha = __builtin_amdgcn_exp2f(-delta);
+                l_run *= alpha;
+#pragma unroll
+                for (int i = 0; i < C::NDB; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+            }
+            m_run += delta;
+            if constexpr (C::MFOLD) {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sacc[kb][r] -= delta;
+                const half_t mh = (half_t)(-m_run);
+                const half_t ml = (half_t)(-m_run - (float)mh);
+                if (hh) { qf[C::NKS - 1][0] = mh; qf[C::NKS - 1][1] = ml; }
+            } else {
+                sub = m_run;
+            }
+        }
+        // ---- P and O^T += V^T P^T per 32-key half ----
+        float psum = 0.f;
+        attn_static_for<2>([&](auto kb_) {
+            constexpr int kb = decltype(kb_)::value;
+            // the V^T fragments of this half are fetched while the VALU computes its exponentials
+            s4 vr[4 * C::NDB];
+            attn_static_for<C::NDB>([&](auto db_) {
+                constexpr int db = decltype(db_)::value;
+                attn_static_for<2>([&](auto s_) {
+                    constexpr int s = decltype(s_)::value;
+                    constexpr int OFF = BUF * C::BUFB + (kb * 32 + 16 * s) * C::ROWB;
+                    vr[4 * db + 2 * s] = attn2_tr<OFF>(vaddr[db][0]);
+                    vr[4 * db + 2 * s + 1] = attn2_tr<OFF>(vaddr[db][1]);
+                });
+            });
+            __builtin_amdgcn_sched_barrier(0);
+            h8 pf[2];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = __builtin_amdgcn_exp2f(C::MFOLD ? sacc[kb][r] : sacc[kb][r] - sub);
+                if (!C::ONES) psum += pv;
+                pf[r >> 3][r & 7] = (half_t)pv;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            attn2_wait_lgkm(vr);
+            attn_static_for<C::NDB>([&](auto db_) {
+                constexpr int db = decltype(db_)::value;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const h4 lo_h = __builtin_bit_cast(h4, vr[4 * db + 2 * s]), hi_h = __builtin_bit_cast(h4, vr[4 * db + 2 * s + 1]);
+                    const h8 vf = {lo_h[0], lo_h[1], lo_h[2], lo_h[3], hi_h[0], hi_h[1], hi_h[2], hi_h[3]};
+                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[s], oacc[db], 0, 0, 0);
+                }
+            });
+        });
+        if (!C::ONES) l_run += psum;
+    };
+    for (int t = 0; t < ntiles; t += 2) {
+        tile(t, std::integral_constant<int, 0>{});
+        if (t + 1 < ntiles) tile(t + 1, std::integral_constant<int, 1>{});
+    }
+
+    // ---- epilogue: O[q][d] = O^T[d][q] / l ----
+    float l_tot;
+    if (C::ONES) l_tot = __shfl(oacc[C::ONES_DB][C::ONES_REG], l31, 64);
+    else l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (qrow < p.Sq) {
+        half_t* orow = p.O + ((long long)b * p.Sq + qrow) * p.ldo + head * D;
+#pragma unroll
+        for (int db = 0; db < C::NDB; ++db)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int d0 = db * 32 + 8 * rq + 4 * hh;
+                if (d0 < D) {
+                    h4 o = {(half_t)(oacc[db][4 * rq] * inv), (half_t)(oacc[db][4 * rq + 1] * inv),
+                            (half_t)(oacc[db][4 * rq + 2] * inv), (half_t)(oacc[db][4 * rq + 3] * inv)};
+                    *reinterpret_cast<h4*>(orow + d0) = o;
+                }
+            }
+    }
+}
+
+static int g_attn2 = 1;           // 0: long self-attention on attn_kernel as before (A/B switch)
+extern "C" int lcm_set_attention_impl(int impl) {
+    if (impl != 0 && impl != 1) { lcm_set_error("attention_impl: %d", impl); return LCM_EINVAL; }
+    g_attn2 = impl;
+    return LCM_OK;
+}
+
+template <int D, int WAVES>
+static int launch_attn2_w(const AttnParams& p, hipStream_t s) {
+    using C = Attn2Cfg<D>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn2_kernel<D, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        attr_set = true;
+    }
+    const int nqb = (p.Sq + 32 * WAVES - 1) / (32 * WAVES);
+    char nm[32];
+    snprintf(nm, sizeof(nm), "attn2_kernel<%d, %d>", D, WAVES);
+    lcm_prof_start(nm, s);
+    hipLaunchKernelGGL((attn2_kernel<D, WAVES>), dim3(nqb * p.B * p.heads), dim3(64 * WAVES), C::LDS_BYTES, s, p, nqb);
+    lcm_prof_stop(s);
+    LCM_CHECK_LAUNCH("attention2");
+    return LCM_OK;
+}
+
+template <int D>
+static int launch_attn2(const AttnParams& p, hipStream_t s) {
+    // 256-row workgroups when they still give every CU two (the K/V tiles are staged once per workgroup), else 128-row ones
+    const long long wg8 = (long long)((p.Sq + 255) / 256) * p.B * p.heads;
+    const bool w8 = g_attn_waves == 8 || (g_attn_waves == 0 && wg8 >= 512);
+    return w8 ? launch_attn2_w<D, 8>(p, s) : launch_attn2_w<D, 4>(p, s);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Wide-head flash attention (head_dim 512): the AutoencoderKL mid-block attention (one head, d = 512, S = h*w).
 // The 32x32 kernel above keeps O for all of d in registers (d <= 160); here a wave owns 16 query rows and uses
@@ -278,24 +625,11 @@ static int launch_attn(const AttnParams& p, hipStream_t s) {
 // No S x S matrix in memory (the GEMM -> softmax -> transpose -> GEMM form needs B * S^2 * 2 bytes: 512 MB per image at
 // SDXL's 128^2 latent).  One workgroup = 64 query rows of one (image, head); 132 KB of LDS.
 // ------------------------------------------------------------------------------------------------
-template <int N>
-__device__ __forceinline__ void attn_wait_vmcnt() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
 template <int OFF>
 __device__ __forceinline__ s4 attn_tr_read(unsigned lds_addr) {
     s4 v;
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "n"(OFF));
     return v;
-}
-template <int... I, class F>
-__device__ __forceinline__ void attn_static_for_impl(std::integer_sequence<int, I...>, F&& f) {
-    (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void attn_static_for(F&& f) {
-    attn_static_for_impl(std::make_integer_sequence<int, N>{}, f);
 }
 
 template <int D, int TK>
@@ -489,6 +823,14 @@ extern "C" int lcm_attention_f16(const void* Q, int ldq, const void* K, int ldk,
                     B, heads, Sq, Sk, scale * 1.4426950408889634f, causal ? 1 : 0};
     LCM_REQUIRE(!causal || Sq == Sk, "attention: causal mask needs Sq == Sk");
     hipStream_t s = (hipStream_t)stream;
+    if (g_attn2 && !causal && Sk >= 128 && g_attn_waves != 2) {       // long (self-attention) sequences: the streaming kernel
+        switch (d) {
+            case 40: return launch_attn2<40>(p, s);
+            case 64: return launch_attn2<64>(p, s);
+            case 80: return launch_attn2<80>(p, s);
+            default: break;
+        }
+    }
     switch (d) {
         case 40: return launch_attn<40>(p, s);
         case 64: return launch_attn<64>(p, s);

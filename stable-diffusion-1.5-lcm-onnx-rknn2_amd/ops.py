@@ -380,6 +380,12 @@ def set_attention_waves(waves):
     _lib.check(_lib.load().lcm_set_attention_waves(int(waves)), "lcm_set_attention_waves")
 
 
+def set_attention_impl(impl):
+    """1 (default): long non-causal sequences (Sk >= 128, d in 40 / 64 / 80) on the streaming kernel; 0: everything on the
+    register-staged kernel (A/B switch)."""
+    _lib.check(_lib.load().lcm_set_attention_impl(int(impl)), "lcm_set_attention_impl")
+
+
 def set_seg_mode(mode):
     """0 auto, 1 always segmented accumulation, 2 always split + reduce (bit-identical; include/lcm_hip.h)."""
     _lib.check(_lib.load().lcm_set_seg_mode(int(mode)), "lcm_set_seg_mode")

@@ -1025,13 +1025,15 @@ def test_segmented_accumulation_is_bit_identical_to_split(kind, B, H, W, Cin, Co
 @pytest.mark.parametrize("B,heads,Sq,Sk,d,causal", [(1, 8, 4096, 4096, 40, False), (2, 8, 1024, 1024, 80, False), (1, 8, 3185, 3185, 40, False),
                                                   (1, 8, 256, 77, 160, False), (2, 12, 77, 77, 64, True)])
 def test_attention_workgroup_shape_is_bit_neutral(B, heads, Sq, Sk, d, causal):
-    """64-row (2 waves) and 128-row (4 waves) attention workgroups: a query row's online softmax walks the same K/V tiles in
-    the same order either way, so the choice (made from the grid size, i.e. from the batch) never changes a bit."""
+    """Workgroup shapes of one attention kernel (register-staged kernel: 64 / 128 query rows; streaming kernel of the long
+    non-causal sequences: 128 / 256): a query row's online softmax walks the same K/V tiles in the same order either way, so
+    the choice (made from the grid size, i.e. from the batch) never changes a bit."""
     C = heads * d
     q, k, v = (rnd(B * S, C, seed=i + 1).to(DEV) for i, S in enumerate((Sq, Sk, Sk)))
     outs = []
+    streaming = (not causal) and Sk >= 128 and d in (40, 64, 80)
     try:
-        for waves in (4, 2, 0):
+        for waves in ((4, 8, 0) if streaming else (4, 2, 0)):
             ops.set_attention_waves(waves)
             o = torch.empty(B * Sq, C, dtype=torch.float16, device=DEV)
             ops.attention(q, k, v, o, B, heads, Sq, Sk, d, ldq=C, ldk=C, ldv=C, ldo=C, causal=causal)
