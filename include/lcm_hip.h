@@ -164,6 +164,9 @@ int lcm_groupnorm_affine_f16(const void* x, int C1, const void* x2, int C2, cons
 /* launches of the LDS-halo conv with fewer workgroups than this use its pipelined variant (3-stage weight ring,
  * double-buffered halo) instead of the single-buffer high-occupancy one; default 768 */
 int lcm_set_halo_pipe_threshold(int wgs);
+/* GroupNorm-fused convolution (lcm_conv3x3_gn_f16 with scale / shift): 1 (default) = the raw halo of the next 64-channel chunk
+ * is fetched into registers under the taps of the current one (measured slower: 202 VGPRs, two workgroups per CU instead of three), 0 (default) = fetched where it is consumed.  Bit-neutral. */
+int lcm_set_halo_prefetch(int on);
 /* 1 (default): stride-1 3x3 convolutions use the LDS-halo kernel; 0: the row-gather implicit GEMM everywhere */
 int lcm_set_conv_impl(int impl);
 

@@ -52,6 +52,31 @@ __device__ __forceinline__ float gelu_erf_f(float x) {
     return 0.5f * x * (1.0f + erfv);
 }
 
+// Sums over the 16 lanes of a DPP row (lanes 16g .. 16g+15) of eight values at once, results in every lane of the row: the
+// xor-butterfly 1, 2, 4, 8 as four v_add_f32_dpp per value (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror,
+// row_mirror) instead of four ds_bpermute round trips through the LDS each.  Same additions in the same tree as
+// `v += __shfl_xor(v, o)` for o = 1, 2, 4, 8 (after the quad steps all lanes of a quad hold one value, so the mirrored partner
+// holds what the xor partner holds): bit-identical.  Inline asm: hipcc emits v_mov_b32_dpp + v_add_f32 for the builtin (twice the
+// VALU).  The eight chains are interleaved, so a step reads a register eight instructions after the step before wrote it; the
+// s_nop 1 in front covers the 2 wait states between the compiler's last VALU write of an operand and the first DPP read.
+#define LCM_DPP_STEP8(CTRL)                                                                                              \
+    asm("s_nop 1\n\t"                                                                                                    \
+        "v_add_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                                  \
+        "v_add_f32_dpp %1, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                                  \
+        "v_add_f32_dpp %2, %2, %2 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                                  \
+        "v_add_f32_dpp %3, %3, %3 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                                  \
+        "v_add_f32_dpp %4, %4, %4 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                                  \
+        "v_add_f32_dpp %5, %5, %5 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                                  \
+        "v_add_f32_dpp %6, %6, %6 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                                  \
+        "v_add_f32_dpp %7, %7, %7 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1"                                       \
+        : "+v"(a[0]), "+v"(b[0]), "+v"(a[1]), "+v"(b[1]), "+v"(a[2]), "+v"(b[2]), "+v"(a[3]), "+v"(b[3]))
+__device__ __forceinline__ void row16_sum8(float (&a)[4], float (&b)[4]) {
+    LCM_DPP_STEP8("quad_perm:[1,0,3,2]");
+    LCM_DPP_STEP8("quad_perm:[2,3,0,1]");
+    LCM_DPP_STEP8("row_half_mirror");
+    LCM_DPP_STEP8("row_mirror");
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -56,8 +56,10 @@ static inline int halo_slabs_per_image(int IH, int IW, int TW, bool ph) {
     return ((IH + rs - 1) / rs) * ((IW + TW - 1) / TW) * (ph ? 4 : 1);
 }
 
-template <int TH, int TW, int BN, int XFORM, int PH>
-__global__ __launch_bounds__(256, 3) void conv_halo_kernel(HaloParams hp) {
+// PF = 1 (XFORM only): the raw halo of the next chunk is prefetched into registers under the taps of the current one
+template <int TH, int TW, int BN, int XFORM, int PH, int PF = 0>
+__global__ __launch_bounds__(256, PF ? 2 : 3) void conv_halo_kernel(HaloParams hp) {
+    static_assert(!PF || XFORM, "halo prefetch: register-staged (GroupNorm-fused) path only");
     constexpr int NT = PH ? 4 : 9;
     constexpr int BM = TH * TW;
     constexpr int TM = BM / 32, TN = BN / 32, RW = BN / 32;
@@ -123,6 +125,27 @@ __global__ __launch_bounds__(256, 3) void conv_halo_kernel(HaloParams hp) {
     const int c_end = (int)((long long)(blockIdx.y + 1) * nchunks / p.splits);
     bool first = true;
 
+    // XFORM: the raw halo of chunk c+1 is fetched into registers while the 9 taps of chunk c run (issued behind the barrier
+    // of tap 1, consumed at the next tap 0): the global-memory latency of the register-staged path -- the tensors that take
+    // this path do not fit the Infinity Cache -- is no longer exposed once per chunk.
+    h8 hv[XFORM ? NV : 1];
+    auto fetch_halo = [&](int c64) {
+        if constexpr (XFORM != 0) {
+            const int cb = c64 << 6;
+            const bool second = cb >= hp.C1;
+            const half_t* src_base = second ? p.A2 : p.A;
+            const int src_ld = second ? C2 : hp.C1;
+            const int src_c = second ? cb - hp.C1 : cb;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (h_pix[i] >= 0) v = *reinterpret_cast<const h8*>(src_base + (long long)h_pix[i] * src_ld + src_c + pos * 8);
+                hv[i] = v;
+            }
+        }
+    };
+    if (PF && c_begin < c_end) fetch_halo(c_begin);
+
     for (int c64 = c_begin; c64 < c_end; ++c64) {
         const int cb = c64 << 6;
         const bool second = cb >= hp.C1;
@@ -132,15 +155,10 @@ __global__ __launch_bounds__(256, 3) void conv_halo_kernel(HaloParams hp) {
         for (int tap = 0; tap < NT; ++tap) {
             if (!first) __syncthreads();          // all waves finished reading the W tile (and the halo when tap == 0)
             first = false;
+            if (PF && tap == 1 && c64 + 1 < c_end) fetch_halo(c64 + 1);
             if (tap == 0) {
                 if (XFORM) {
-                    h8 hv[NV];
-#pragma unroll
-                    for (int i = 0; i < NV; ++i) {
-                        h8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-                        if (h_pix[i] >= 0) v = *reinterpret_cast<const h8*>(src_base + (long long)h_pix[i] * src_ld + src_c + pos * 8);
-                        hv[i] = v;
-                    }
+                    if (!PF) fetch_halo(c64);
                     const float* sc = hp.gn_scale + (long long)bimg * p.Cin + cb + pos * 8;
                     const float* sh = hp.gn_shift + (long long)bimg * p.Cin + cb + pos * 8;
                     float s8[8], t8[8];
@@ -465,6 +483,8 @@ extern bool lcm_plan_get(int kind, int M, int N, int K, int aux, int* bm, int* b
 static int g_halo_pipe_below = 768;      // workgroup count under which the pipelined (WS=3) variant is used
 
 extern "C" int lcm_set_halo_pipe_threshold(int wgs) { g_halo_pipe_below = wgs; return LCM_OK; }
+static int g_halo_prefetch = 0;          // GroupNorm-fused conv: prefetch the next chunk's raw halo (A/B switch; bit-neutral)
+extern "C" int lcm_set_halo_prefetch(int on) { g_halo_prefetch = on ? 1 : 0; return LCM_OK; }
 
 template <int TH, int TW, int BN, int XFORM, int PH>
 static void launch_halo(HaloParams& hp, hipStream_t s, int force) {     // force: 1 single-buffer, 2 pipelined, 3 pipelined with a row of taps per step, else by grid size
@@ -530,6 +550,13 @@ static void launch_halo(HaloParams& hp, hipStream_t s, int force) {     // force
     }
     constexpr int smem = HROWS_PAD * 128 + BN * 128;
     char nm[64];
+    if constexpr (XFORM != 0) if (g_halo_prefetch) {
+        snprintf(nm, sizeof(nm), "conv_halo_kernel<%d, %d, %d, %d, %d, 1>%s", TH, TW, BN, XFORM, PH, hp.g.splits > 1 ? " +splitk" : "");
+        lcm_prof_start(nm, s);
+        hipLaunchKernelGGL((conv_halo_kernel<TH, TW, BN, XFORM, PH, 1>), grid, dim3(256), smem, s, hp);
+        lcm_prof_stop(s);
+        return;
+    }
     snprintf(nm, sizeof(nm), "conv_halo_kernel<%d, %d, %d, %d, %d>%s", TH, TW, BN, XFORM, PH, hp.g.splits > 1 ? " +splitk" : "");
     lcm_prof_start(nm, s);
     hipLaunchKernelGGL((conv_halo_kernel<TH, TW, BN, XFORM, PH>), grid, dim3(256), smem, s, hp);

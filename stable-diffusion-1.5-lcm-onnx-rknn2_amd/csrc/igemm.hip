@@ -486,14 +486,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(IgemmParams p, int t
         for (int j = 0; j < 4; ++j) { const float f = (float)o[j]; ssum[j] += f; ssq[j] += f * f; }
     }
     if (p.stats) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) {
-                ssum[j] += __shfl_xor(ssum[j], o, 64);
-                ssq[j] += __shfl_xor(ssq[j], o, 64);
-            }
-        }
+row16_sum8(ssum, ssq);
         if (l == 0) {
             float* dst = p.stats + ((long long)slab * p.N + n) * 2;
             *reinterpret_cast<f4*>(dst) = (f4){ssum[0], ssq[0], ssum[1], ssq[1]};

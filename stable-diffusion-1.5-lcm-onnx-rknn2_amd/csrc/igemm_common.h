@@ -158,14 +158,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f4 (&acc)[B
                     }
                 }
                 if (do_stats && slab_of[bp] >= 0) {   // fold the 16 pixel-lanes of the channel quad; one lane writes (sum, sumsq) x 4
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-#pragma unroll
-                        for (int o = 1; o < 16; o <<= 1) {
-                            ssum[j] += __shfl_xor(ssum[j], o, 64);
-                            ssq[j] += __shfl_xor(ssq[j], o, 64);
-                        }
-                    }
+row16_sum8(ssum, ssq);
                     if ((lane & 15) == 0) {
                         float* dst = p.stats + ((long long)slab_of[bp] * p.N + n) * 2;
                         *reinterpret_cast<f4*>(dst) = (f4){ssum[0], ssq[0], ssum[1], ssq[1]};

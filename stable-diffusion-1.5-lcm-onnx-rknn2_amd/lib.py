@@ -71,6 +71,7 @@ _SIGS = {
     "lcm_set_conv_impl": [_i],
     "lcm_set_persist_n": [_i],
     "lcm_set_halo_pipe_threshold": [_i],
+    "lcm_set_halo_prefetch": [_i],
     "lcm_set_gn_fused_bytes": [_i64],
     "lcm_plan_set": [_i] * 9,
     "lcm_plan_clear": [],

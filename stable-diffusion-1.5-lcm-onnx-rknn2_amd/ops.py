@@ -231,6 +231,10 @@ def set_halo_pipe_threshold(wgs):
     _lib.check(_lib.load().lcm_set_halo_pipe_threshold(int(wgs)), "lcm_set_halo_pipe_threshold")
 
 
+def set_halo_prefetch(on):
+    _lib.check(_lib.load().lcm_set_halo_prefetch(1 if on else 0), "lcm_set_halo_prefetch")
+
+
 def set_persist_n(on):
     _lib.check(_lib.load().lcm_set_persist_n(1 if on else 0), "lcm_set_persist_n")
 
