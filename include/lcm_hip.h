@@ -48,7 +48,7 @@ int lcm_gemm_f16(const void* A, int lda, const void* A2, int lda2, int K1,
                  const void* res, int ldr, void* out, int ldo,
                  int M, int N, int K, int epilogue, float out_scale,
                  int batch, int64_t strideA, int64_t strideW, int64_t strideO, int img_rows,
-                 void* stats_out, int* slabs_per_image, void* stream);
+                 void* stats_out, int64_t stats_bytes, int* slabs_per_image, void* stream);
 /* img_rows = output rows PER IMAGE when the M rows stack several independent requests (M % img_rows == 0; 0: M is
  * one image).  It keys everything that decides the fp32 summation order (see "Determinism" below).
  *
@@ -58,7 +58,10 @@ int lcm_gemm_f16(const void* A, int lda, const void* A2, int lda2, int K1,
  * a split-K reduce slab): fp32 [B * slabs_per_image][N][2].  Slabs are a property of the output tensor, never of
  * the tile shape.  *slabs_per_image returns how many slabs each image got; 0 means the launch could not produce them
  * (img_rows % 32 != 0, GEGLU/batched launch, N > 2048): use lcm_groupnorm_f16 on the output instead.
- * Consumer: lcm_groupnorm_from_stats_f16.  Buffer size: 8 * N * (max(M / 16, 256) + 64) bytes always suffices. */
+ * Consumer: lcm_groupnorm_from_stats_f16.  stats_bytes = size of the buffer behind stats_out: a launch whose slabs would not
+ * fit is refused with LCM_EINVAL BEFORE anything is enqueued (round 2 wrote past an undersized buffer: a GPU memory fault on
+ * odd image sizes).  lcm_stats_bytes(M, N, img_rows) returns a size that always suffices. */
+int64_t lcm_stats_bytes(int M, int N, int img_rows);
 
 /* fp32 scratch for deterministic split-K (deep-K, small-M layers).  The caller owns the memory; it is
  * registered per current device and must outlive every later launch (graph replays included).  With no workspace
@@ -142,7 +145,7 @@ int lcm_gemm_tile_config(int M, int N, int batch);
 int lcm_conv3x3_f16(const void* in, const void* W, const void* bias,
                     const void* rowadd, int ld_rowadd, const void* res, void* out,
                     int B, int Hin, int Win, int Cin, int Cout, int stride, int ups,
-                    void* stats_out, int* slabs_per_image, void* stream);
+                    void* stats_out, int64_t stats_bytes, int* slabs_per_image, void* stream);
 
 /* ---- fused GroupNorm(+SiLU) -> 3x3 convolution, stride 1 (ResnetBlock2D norm1->act->conv1, norm2->act->conv2) ----
  * LDS-halo implicit GEMM (csrc/conv_halo.hip).  Input = channel concat [in | in2] (in2 NULL: single source; fused
@@ -154,8 +157,8 @@ int lcm_conv3x3_f16(const void* in, const void* W, const void* bias,
  */
 int lcm_conv3x3_gn_f16(const void* in, int C1, const void* in2, int C2, const void* gn_scale, const void* gn_shift,
                        int silu, const void* W, const void* bias, const void* rowadd, int ld_rowadd, const void* res,
-                       void* out, int B, int Hin, int Win, int Cout, int ups, void* stats_out, int* slabs_per_image,
-                       void* stream);
+                       void* out, int B, int Hin, int Win, int Cout, int ups, void* stats_out, int64_t stats_bytes,
+                       int* slabs_per_image, void* stream);
 /* GroupNorm statistics folded into per-(image, channel) fp32 scale/shift tables [B][C1+C2] for the call above;
  * ws as for lcm_groupnorm_f16. */
 int lcm_groupnorm_affine_f16(const void* x, int C1, const void* x2, int C2, const void* gamma, const void* beta,

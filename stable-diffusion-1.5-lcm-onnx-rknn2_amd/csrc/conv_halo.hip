@@ -652,7 +652,10 @@ int lcm_conv_halo_launch(HaloParams& hp, int B, hipStream_t s, int* slabs_per_im
     p.rg_kind = TW == 16 ? 1 : 2; p.rg_ph = ph ? 1 : 0; p.rg_IH = IH; p.rg_IW = IW; p.rg_OH = hp.H; p.rg_OW = hp.W;
     if (p.stats) {   // fused GroupNorm statistics of the output: canonical 32-pixel slabs (halo_slabs / splitk_reduce_kernel)
         if (p.N > 2048) p.stats = nullptr;
-        else if (slabs_per_image) *slabs_per_image = halo_slabs_per_image(IH, IW, TW, ph);
+        else {
+            if (slabs_per_image) *slabs_per_image = halo_slabs_per_image(IH, IW, TW, ph);
+            LCM_STATS_FIT(p, halo_slabs_per_image(IH, IW, TW, ph), B, "conv3x3");
+        }
     }
     const bool xf = hp.gn_scale != nullptr;
     if (ph && xf) return 1;

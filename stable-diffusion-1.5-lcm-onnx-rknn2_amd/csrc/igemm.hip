@@ -813,6 +813,7 @@ static int launch_igemm(IgemmParams& p, int batch, hipStream_t s, int img_rows, 
         const bool ok = p.epi == 0 && batch == 1 && p.N <= 2048 && img_rows % 32 == 0;
         if (ok && slabs_per_image) *slabs_per_image = img_rows / 32;       // canonical 32-row slabs (igemm_epilogue / reduce)
         if (!ok) p.stats = nullptr;
+        else LCM_STATS_FIT(p, img_rows / 32, p.M / img_rows, "gemm");
     }
     p.seg_parts = 1;
     if (splits > 1) {    // a batched launch that fills the chip unsplit keeps the canonical partition in registers instead
@@ -851,7 +852,7 @@ extern "C" int lcm_gemm_f16(const void* A, int lda, const void* A2, int lda2, in
                             const void* res, int ldr, void* out, int ldo,
                             int M, int N, int K, int epilogue, float out_scale,
                             int batch, int64_t strideA, int64_t strideW, int64_t strideO, int img_rows,
-                            void* stats_out, int* slabs_per_image, void* stream) {
+                            void* stats_out, int64_t stats_bytes, int* slabs_per_image, void* stream) {
     LCM_REQUIRE(A && W && out, "gemm: null pointer");
     LCM_REQUIRE(M > 0 && N > 0 && K > 0 && batch > 0, "gemm: bad shape M=%d N=%d K=%d batch=%d", M, N, K, batch);
     LCM_REQUIRE(K % 64 == 0, "gemm: K=%d must be a multiple of 64", K);
@@ -870,7 +871,8 @@ extern "C" int lcm_gemm_f16(const void* A, int lda, const void* A2, int lda2, in
     p.ldo = ldo; p.ldr = ldr; p.ld_rowadd = ld_rowadd; p.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1;
     p.epi = epilogue; p.out_scale = out_scale;
     p.strideA = strideA; p.strideW = strideW; p.strideO = strideO;
-    p.stats = (float*)stats_out;
+    p.stats = (float*)stats_out; p.stats_cap = stats_bytes;
+    LCM_REQUIRE(!stats_out || slabs_per_image, "gemm: stats_out needs slabs_per_image");
     // strided (batched-matrix) calls never split: whether a request runs alone or in a batch must not change its K partition
     const bool allow_split = batch == 1 && strideA == 0 && strideW == 0 && strideO == 0;
     return launch_igemm<0>(p, batch, (hipStream_t)stream, img_rows, allow_split, stats_out != nullptr, slabs_per_image);
@@ -896,6 +898,16 @@ extern "C" int lcm_gemm_ln_f16(const void* A, int lda, const void* W, const void
     return launch_igemm<0>(p, 1, (hipStream_t)stream, img_rows, false, false, nullptr);
 }
 
+// Bytes that always suffice for the fused statistics of an [M, N] contraction output made of M / img_rows images (img_rows 0:
+// one image): per image at most max(img_rows / 16, 256) + 64 slabs (canonical 32-pixel slabs incl. partial patches at the image
+// border of a convolution, four phase slabs per patch of an upsampling one; a split-K reduce emits the same slabs).
+extern "C" int64_t lcm_stats_bytes(int M, int N, int img_rows) {
+    if (M <= 0 || N <= 0) return 0;
+    if (img_rows <= 0 || M % img_rows) img_rows = M;
+    const long long per_img = (img_rows / 16 > 256 ? img_rows / 16 : 256) + 64;
+    return (int64_t)(per_img * (M / img_rows) * N * 2 * (long long)sizeof(float));
+}
+
 struct HaloParams {
     IgemmParams g;
     int C1;
@@ -910,7 +922,7 @@ int lcm_conv_halo_launch(HaloParams& hp, int B, hipStream_t s, int* slabs_per_im
 extern "C" int lcm_conv3x3_gn_f16(const void* in, int C1, const void* in2, int C2, const void* gn_scale,
                                   const void* gn_shift, int silu, const void* W, const void* bias, const void* rowadd,
                                   int ld_rowadd, const void* res, void* out, int B, int Hin, int Win, int Cout, int ups,
-                                  void* stats_out, int* slabs_per_image, void* stream) {
+                                  void* stats_out, int64_t stats_bytes, int* slabs_per_image, void* stream) {
     LCM_REQUIRE(in && W && out, "conv3x3_gn: null pointer");
     if (!in2) C2 = 0;
     const int Cin = C1 + C2;
@@ -937,7 +949,8 @@ extern "C" int lcm_conv3x3_gn_f16(const void* in, int C1, const void* in2, int C
     p.ldo = Cout; p.ldr = Cout; p.ld_rowadd = ld_rowadd; p.rows_per_batch = hp.H * hp.W;
     p.epi = 0; p.out_scale = 1.0f; p.splits = 1;
     hp.C1 = C1; hp.gn_scale = (const float*)gn_scale; hp.gn_shift = (const float*)gn_shift; hp.silu = silu;
-    p.stats = (float*)stats_out;
+    p.stats = (float*)stats_out; p.stats_cap = stats_bytes;
+    LCM_REQUIRE(!stats_out || slabs_per_image, "conv3x3_gn: stats_out needs slabs_per_image");
     if (slabs_per_image) *slabs_per_image = 0;
     const int hrc = lcm_conv_halo_launch(hp, B, (hipStream_t)stream, slabs_per_image);
     if (hrc < 0) return hrc;
@@ -952,7 +965,7 @@ extern "C" int lcm_conv3x3_gn_f16(const void* in, int C1, const void* in2, int C
 extern "C" int lcm_conv3x3_f16(const void* in, const void* W, const void* bias,
                                const void* rowadd, int ld_rowadd, const void* res, void* out,
                                int B, int Hin, int Win, int Cin, int Cout, int stride, int ups,
-                               void* stats_out, int* slabs_per_image, void* stream) {
+                               void* stats_out, int64_t stats_bytes, int* slabs_per_image, void* stream) {
     LCM_REQUIRE(in && W && out, "conv3x3: null pointer");
     LCM_REQUIRE(B > 0 && Hin > 0 && Win > 0, "conv3x3: bad shape");
     LCM_REQUIRE(Cin % 64 == 0 && Cout % 64 == 0, "conv3x3: Cin=%d Cout=%d must be multiples of 64", Cin, Cout);
@@ -961,7 +974,7 @@ extern "C" int lcm_conv3x3_f16(const void* in, const void* W, const void* bias,
     if (rowadd) LCM_REQUIRE(ld_rowadd % 4 == 0, "conv3x3: ld_rowadd misaligned");
     if (stride == 1 && (g_conv_impl == 1 || (ups & 3) == 2 || (ups & 12)))
         return lcm_conv3x3_gn_f16(in, Cin, nullptr, 0, nullptr, nullptr, 0, W, bias, rowadd, ld_rowadd, res, out, B, Hin, Win,
-                                  Cout, ups, stats_out, slabs_per_image, stream);
+                                  Cout, ups, stats_out, stats_bytes, slabs_per_image, stream);
     const int Hl = ups ? 2 * Hin : Hin, Wl = ups ? 2 * Win : Win;
     IgemmParams p = {};
     p.A = (const half_t*)in; p.W = (const half_t*)W; p.bias = (const half_t*)bias;
@@ -971,6 +984,7 @@ extern "C" int lcm_conv3x3_f16(const void* in, const void* W, const void* bias,
     p.M = B * p.Hout * p.Wout; p.N = Cout; p.K = 9 * Cin;
     p.ldo = Cout; p.ldr = Cout; p.ld_rowadd = ld_rowadd; p.rows_per_batch = p.Hout * p.Wout;
     p.epi = 0; p.out_scale = 1.0f;
-    p.stats = (float*)stats_out;
+    p.stats = (float*)stats_out; p.stats_cap = stats_bytes;
+    LCM_REQUIRE(!stats_out || slabs_per_image, "conv3x3: stats_out needs slabs_per_image");
     return launch_igemm<1>(p, 1, (hipStream_t)stream, p.Hout * p.Wout, true, stats_out != nullptr, slabs_per_image);
 }

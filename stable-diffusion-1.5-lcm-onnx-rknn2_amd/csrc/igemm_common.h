@@ -39,7 +39,19 @@ struct IgemmParams {
     const float* ln_c;   // [N] fp32: sum_k beta[k] W[n][k] + bias[n]
     float ln_eps;
     int n_iters;         // igemm2: consecutive n-tiles one workgroup walks with a continuous LDS-DMA pipeline (>= 1)
+    long long stats_cap; // host side: bytes the caller allocated behind `stats` (the launch is refused when the slabs do not fit)
 };
+
+// fused-statistics bounds check shared by the contraction entry points: slabs_per_image x images x N x (sum, sumsq) fp32
+#define LCM_STATS_FIT(p, slabs, images, what)                                                                              \
+    do {                                                                                                                   \
+        const long long need__ = (long long)(slabs) * (images) * (p).N * 2 * (long long)sizeof(float);                     \
+        if ((p).stats && need__ > (p).stats_cap) {                                                                         \
+            lcm_set_error("%s: statistics buffer too small: %d slabs x %d images x %d channels need %lld bytes, have %lld " \
+                          "(size it with lcm_stats_bytes)", what, (int)(slabs), (int)(images), (p).N, need__, (p).stats_cap); \
+            return LCM_EINVAL;                                                                                             \
+        }                                                                                                                  \
+    } while (0)
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     // contiguous chunk of tiles per XCD (blocks are dealt round-robin over the 8 XCDs)

@@ -32,10 +32,10 @@ _vp, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
 
 _SIGS = {
     "lcm_gemm_f16": [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _i,
-                     _i64, _i64, _i64, _i, _vp, C.POINTER(_i), _vp],
+                     _i64, _i64, _i64, _i, _vp, _i64, C.POINTER(_i), _vp],
     "lcm_gemm_ln_f16": [_vp, _i, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "lcm_ln_fold_refresh": [_vp, _i, _i, _vp, _vp, _f, _vp, _vp, _vp],
-    "lcm_conv3x3_f16": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, C.POINTER(_i), _vp],
+    "lcm_conv3x3_f16": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i64, C.POINTER(_i), _vp],
     "lcm_groupnorm_from_stats_f16": [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp],
     "lcm_conv3x3_c4_f32in": [_vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "lcm_conv3x3_smalln": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
@@ -76,12 +76,12 @@ _SIGS = {
     "lcm_plan_set": [_i] * 9,
     "lcm_plan_clear": [],
     "lcm_canonical_splits": [_i] * 6,
-    "lcm_conv3x3_gn_f16": [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp,
+    "lcm_conv3x3_gn_f16": [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i64,
                            C.POINTER(_i), _vp],
     "lcm_groupnorm_affine_f16": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp],
     "lcm_device_info": [_i, C.c_char_p, _i, C.POINTER(_i), C.POINTER(C.c_uint64)],
 }
-EXPORTS = tuple(sorted(list(_SIGS) + ["lcm_last_error", "lcm_version", "lcm_groupnorm_ws_bytes"]))
+EXPORTS = tuple(sorted(list(_SIGS) + ["lcm_last_error", "lcm_version", "lcm_groupnorm_ws_bytes", "lcm_stats_bytes"]))
 
 _lib = None
 
@@ -107,6 +107,8 @@ def load():
     lib.lcm_version.restype = _i
     lib.lcm_groupnorm_ws_bytes.restype = _i64
     lib.lcm_groupnorm_ws_bytes.argtypes = [_i, _i, _i, _i]
+    lib.lcm_stats_bytes.restype = _i64
+    lib.lcm_stats_bytes.argtypes = [_i, _i, _i]
     _install_plans(lib)
     _lib = lib
     return lib

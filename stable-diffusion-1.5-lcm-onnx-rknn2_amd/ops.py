@@ -84,25 +84,17 @@ class Stats:
 
 def stats_floats(M, N, hw=None):
     """fp32 elements that always suffice for the fused statistics of an [M, N] output made of M // hw images of hw rows
-    (hw None: one image).  Per image: canonical 32-pixel slabs (<= hw/16 incl. partial patches at the image border) or
-    split-K reduce slabs (<= 255, a function of hw); slab counts are per image because the slab structure must not
-    depend on the batch."""
-    hw = int(hw) if hw else int(M)
-    B = max(1, int(M) // max(1, hw))
-    return 2 * N * B * (max(hw // 16, 256) + 64)
-
-
-def _stats_check(stats, M, N, hw, what):
-    if stats is not None and stats.P * max(1, M // max(1, hw)) * N * 2 > stats.buf.numel():
-        raise _lib.LcmHipError(f"{what}: statistics buffer too small ({stats.buf.numel()} floats for {stats.P} slabs x "
-                               f"{M // max(1, hw)} images x {N} channels): size it with ops.stats_floats(M, N, hw)")
+    (hw None: one image): lcm_stats_bytes of the library (slab counts are per image: the slab structure never depends on
+    the batch)."""
+    return int(_lib.load().lcm_stats_bytes(int(M), int(N), int(hw) if hw else 0)) // 4
 
 
 def _stats_args(stats):
+    """(pointer, bytes behind it, slab-count out parameter): the library refuses a launch whose slabs would not fit."""
     if stats is None:
-        return None, None
+        return None, 0, None
     sp = C.c_int(0)
-    return _p(stats.buf), sp
+    return _p(stats.buf), stats.buf.numel() * stats.buf.element_size(), sp
 
 
 def gemm(a, w, out, *, bias=None, res=None, rowadd=None, rows_per_batch=0, a2=None, epilogue=0, out_scale=1.0,
@@ -112,7 +104,7 @@ def gemm(a, w, out, *, bias=None, res=None, rowadd=None, rows_per_batch=0, a2=No
     bit-identical at any batch size).  stats: optional ``Stats`` to receive the fused GroupNorm statistics of ``out``
     (stats.P == 0 afterwards: not produced)."""
     L = _lib.load()
-    sbuf, sp = _stats_args(stats)
+    sbuf, sbytes, sp = _stats_args(stats)
     M = a.shape[0] if M is None else M
     K1 = a.shape[-1] if a2 is not None else 0
     K = (a.shape[-1] + (a2.shape[-1] if a2 is not None else 0)) if K is None else K
@@ -132,11 +124,10 @@ def gemm(a, w, out, *, bias=None, res=None, rowadd=None, rows_per_batch=0, a2=No
                             rowadd.stride(0) if rowadd is not None else 0, rows_per_batch,
                             _p(res), res.stride(0) if res is not None else 0, _p(out), ldo,
                             M, N, K, epilogue, float(out_scale), batch, strideA, strideW, strideO, int(img_rows),
-                            sbuf, C.byref(sp) if sp is not None else None, _stream())
+                            sbuf, sbytes, C.byref(sp) if sp is not None else None, _stream())
     if stats is not None:
         stats.P = sp.value
     _lib.check(rc, "lcm_gemm_f16")
-    _stats_check(stats, M, N, img_rows if img_rows and M % img_rows == 0 else M, "gemm")
     return out
 
 
@@ -167,7 +158,7 @@ def conv3x3(x, w, out, B, H, W, Cin, Cout, *, bias=None, rowadd=None, res=None, 
     with output_size; F.interpolate(size=..., mode="nearest") is the 2x result cropped by one row / column, and the conv
     then pads THAT with zeros -- so only the loader-fused form (ups=1, plain 3x3 weights) can serve it."""
     L = _lib.load()
-    sbuf, sp = _stats_args(stats)
+    sbuf, sbytes, sp = _stats_args(stats)
     Ho, Wo = ((2 * H, 2 * W) if ups else ((H + 1) // 2, (W + 1) // 2) if stride == 2 else (H, W))
     flags = ups
     if out_hw is not None and tuple(out_hw) != (Ho, Wo):
@@ -186,12 +177,11 @@ def conv3x3(x, w, out, B, H, W, Cin, Cout, *, bias=None, rowadd=None, res=None, 
     with _Timed("conv3x3", tile_config(Mo, Cout) if PROFILE is not None else "", 2.0 * Mo * Cout * taps * Cin,
                 2.0 * (B * H * W * Cin + 9 * Cin * Cout + Mo * Cout)):
         rc = L.lcm_conv3x3_f16(_p(x), _p(w), _p(bias), _p(rowadd), rowadd.stride(0) if rowadd is not None else 0,
-                               _p(res), _p(out), B, H, W, Cin, Cout, stride, flags, sbuf,
+                               _p(res), _p(out), B, H, W, Cin, Cout, stride, flags, sbuf, sbytes,
                                C.byref(sp) if sp is not None else None, _stream())
     if stats is not None:
         stats.P = sp.value
     _lib.check(rc, "lcm_conv3x3_f16")
-    _stats_check(stats, Mo, Cout, Ho * Wo, "conv3x3")
     return out
 
 
@@ -199,7 +189,7 @@ def conv3x3_gn(x, w, out, B, H, W, C1, Cout, *, x2=None, C2=0, gn_scale=None, gn
                rowadd=None, res=None, ups=0, stats=None):
     """Fused [GroupNorm-apply (+SiLU)] -> conv3x3 (stride 1) over the channel concat [x | x2]."""
     L = _lib.load()
-    sbuf, sp = _stats_args(stats)
+    sbuf, sbytes, sp = _stats_args(stats)
     Cin = C1 + (C2 if x2 is not None else 0)
     Ho, Wo = (2 * H, 2 * W) if ups else (H, W)
     Mo = B * Ho * Wo
@@ -212,11 +202,10 @@ def conv3x3_gn(x, w, out, B, H, W, C1, Cout, *, x2=None, C2=0, gn_scale=None, gn
         rc = L.lcm_conv3x3_gn_f16(_p(x), C1, _p(x2), C2 if x2 is not None else 0, _p(gn_scale), _p(gn_shift),
                                   1 if silu else 0, _p(w), _p(bias), _p(rowadd),
                                   rowadd.stride(0) if rowadd is not None else 0, _p(res), _p(out), B, H, W, Cout, ups,
-                                  sbuf, C.byref(sp) if sp is not None else None, _stream())
+                                  sbuf, sbytes, C.byref(sp) if sp is not None else None, _stream())
     if stats is not None:
         stats.P = sp.value
     _lib.check(rc, "lcm_conv3x3_gn_f16")
-    _stats_check(stats, Mo, Cout, Ho * Wo, "conv3x3_gn")
     return out
 
 

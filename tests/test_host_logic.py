@@ -31,17 +31,42 @@ def test_abi_argument_validation_without_gpu():
     import ctypes as C
     from sdlcm_amd import lib
     L = lib.load()
-    rc = L.lcm_gemm_f16(None, 0, None, 0, 0, None, None, None, 0, 0, None, 0, None, 0, 1, 64, 64, 0, 1.0, 1, 0, 0, 0, 0, None, None, None)
+    rc = L.lcm_gemm_f16(None, 0, None, 0, 0, None, None, None, 0, 0, None, 0, None, 0, 1, 64, 64, 0, 1.0, 1, 0, 0, 0, 0, None, 0, None, None)
     assert rc == -1 and b"null pointer" in L.lcm_last_error()
     buf = C.create_string_buffer(16)
     p = C.cast(buf, C.c_void_p)
-    rc = L.lcm_gemm_f16(p, 8, None, 0, 0, p, None, None, 0, 0, None, 0, p, 8, 4, 64, 100, 0, 1.0, 1, 0, 0, 0, 0, None, None, None)
+    rc = L.lcm_gemm_f16(p, 8, None, 0, 0, p, None, None, 0, 0, None, 0, p, 8, 4, 64, 100, 0, 1.0, 1, 0, 0, 0, 0, None, 0, None, None)
     assert rc == -1 and b"multiple of 64" in L.lcm_last_error()
     rc = L.lcm_attention_f16(p, 8, p, 8, p, 8, p, 8, 1, 8, 4, 4, 48, 1.0, 0, None)
     assert rc == -1 and b"head_dim" in L.lcm_last_error()
     with pytest.raises(lib.LcmHipError):
         lib.check(rc, "attention")
     assert L.lcm_gemm_tile_config(262144, 128, 1) == 128128
+
+
+def test_undersized_statistics_buffer_is_refused_before_any_launch():
+    """The API hole behind round 2's GPU fault: the contraction entry points take the size of the statistics buffer and return
+    LCM_EINVAL when the launch's slabs would not fit (checked before anything is enqueued, so it runs on the CPU box too)."""
+    import ctypes as C
+    from sdlcm_amd import lib
+    L = lib.load()
+    buf = C.create_string_buffer(1 << 16)
+    p = C.cast(buf, C.c_void_p)
+    sp = C.c_int(0)
+    # GEMM [64, 64] of one image: 2 slabs x 64 channels x (sum, sumsq) fp32 = 1024 bytes
+    rc = L.lcm_gemm_f16(p, 64, None, 0, 0, p, None, None, 0, 0, None, 0, p, 64, 64, 64, 64, 0, 1.0, 1, 0, 0, 0, 64, p, 1023, C.byref(sp), None)
+    assert rc == -1 and b"statistics buffer too small" in L.lcm_last_error() and b"1024 bytes" in L.lcm_last_error()
+    # 3x3 conv of one 16x16 image, 64 -> 64 channels: 8 slabs of 2x16 pixels = 4096 bytes
+    rc = L.lcm_conv3x3_f16(p, p, None, None, 0, None, p, 1, 16, 16, 64, 64, 1, 0, p, 4095, C.byref(sp), None)
+    assert rc == -1 and b"statistics buffer too small" in L.lcm_last_error() and b"4096 bytes" in L.lcm_last_error()
+    rc = L.lcm_conv3x3_gn_f16(p, 64, None, 0, None, None, 0, p, None, None, 0, None, p, 1, 16, 16, 64, 0, p, 4095, C.byref(sp), None)
+    assert rc == -1 and b"statistics buffer too small" in L.lcm_last_error()
+    # a statistics pointer without the slab-count out parameter is an error too
+    rc = L.lcm_gemm_f16(p, 64, None, 0, 0, p, None, None, 0, 0, None, 0, p, 64, 64, 64, 64, 0, 1.0, 1, 0, 0, 0, 64, p, 1 << 16, None, None)
+    assert rc == -1 and b"slabs_per_image" in L.lcm_last_error()
+    # the sizing function always covers the slabs of a launch (odd image sizes included)
+    assert L.lcm_stats_bytes(64, 64, 64) >= 1024 and L.lcm_stats_bytes(45 * 25, 320, 45 * 25) >= (23 * 3) * 320 * 8
+    assert L.lcm_stats_bytes(8 * 4096, 320, 4096) == 8 * L.lcm_stats_bytes(4096, 320, 4096)
 
 
 def test_product_glue_matches_reference_vectors():

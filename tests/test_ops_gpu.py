@@ -1045,3 +1045,34 @@ def test_attention_workgroup_shape_is_bit_neutral(B, heads, Sq, Sk, d, causal):
     qf, kf, vf = (t.float().cpu().reshape(B, -1, heads, d).transpose(1, 2) for t in (q, k, v))
     ref = F.scaled_dot_product_attention(qf, kf, vf, is_causal=causal).transpose(1, 2).reshape(B * Sq, C)
     close(outs[0], ref, what="attention")
+
+
+@pytest.mark.parametrize("H,W,Cin,Cout", [(25, 45, 64, 128), (49, 65, 128, 64), (13, 13, 320, 320)])
+def test_statistics_buffer_exact_size_and_guard(H, W, Cin, Cout):
+    """Odd image sizes (partial slabs at the border -- the case that overflowed the buffer in round 2): with a statistics buffer
+    of EXACTLY slabs x channels x 2 floats the launch succeeds and never writes past it (guard words behind it stay intact);
+    one float less is refused with LCM_EINVAL before anything runs."""
+    from sdlcm_amd.lib import LcmHipError
+    x = rnd(H * W, Cin, seed=1).to(DEV)
+    w = (rnd(Cout, 9 * Cin, seed=2) * (9 * Cin) ** -0.5).to(DEV)
+    out = torch.empty(H * W, Cout, dtype=torch.float16, device=DEV)
+    ws = torch.empty(64 << 18, dtype=torch.float32, device=DEV)
+    ops.set_workspace(ws)
+    try:
+        big = ops.Stats(torch.zeros(ops.stats_floats(H * W, Cout, H * W), dtype=torch.float32, device=DEV))
+        ops.conv3x3(x, w, out, 1, H, W, Cin, Cout, stats=big)
+        assert big.P > 0
+        n = big.P * Cout * 2
+        guard = 4096
+        raw = torch.full((n + guard,), 12345.0, dtype=torch.float32, device=DEV)
+        exact = ops.Stats(raw[:n])
+        ops.conv3x3(x, w, out, 1, H, W, Cin, Cout, stats=exact)
+        torch.cuda.synchronize()
+        assert exact.P == big.P
+        assert torch.equal(raw[:n], big.buf[:n])
+        assert bool((raw[n:] == 12345.0).all()), "statistics written past the buffer"
+        small = ops.Stats(raw[:n - 1])
+        with pytest.raises(LcmHipError, match="statistics buffer too small"):
+            ops.conv3x3(x, w, out, 1, H, W, Cin, Cout, stats=small)
+    finally:
+        ops.set_workspace(None)
