@@ -524,11 +524,12 @@ class HipLcmSDXLWorker(HipLcmWorker):
     @staticmethod
     def _load_text_encoders(eng, device, ckpt_root, clip_sd):
         from ..clip import CLIP_BIGG, CLIP_L, ClipTextHip, HashTokenizer, load_clip_dir, synthetic_clip
-        from ..prompt import _BpeTokenizer
+        from ..prompt import make_tokenizer
         eng.enc, eng.tok = [], []
         for idx, (sub, tsub, cfg0, seed) in enumerate((("text_encoder", "tokenizer", CLIP_L, 2),
                                                        ("text_encoder_2", "tokenizer_2", CLIP_BIGG, 3))):
             d = os.path.join(ckpt_root, sub) if ckpt_root else None
+            real = True
             if clip_sd is not None and clip_sd[idx] is not None:          # carried inside a single-file checkpoint
                 sd = clip_sd[idx]
                 D = sd["embeddings.token_embedding.weight"].shape[1]
@@ -541,10 +542,9 @@ class HipLcmSDXLWorker(HipLcmWorker):
                 sd, cfg = load_clip_dir(d)
                 cfg = dict(cfg0, **cfg)
             else:
-                sd, cfg = synthetic_clip(cfg0, seed=seed), cfg0
+                sd, cfg, real = synthetic_clip(cfg0, seed=seed), cfg0, False
             eng.enc.append(ClipTextHip(sd, cfg, device=device))
-            td = os.path.join(ckpt_root, tsub) if ckpt_root else None
-            eng.tok.append(_BpeTokenizer(td) if td and os.path.isdir(td) else HashTokenizer(cfg["vocab_size"]))
+            eng.tok.append(make_tokenizer(ckpt_root, tsub, cfg["vocab_size"], real))
         if eng.enc[0].D + eng.enc[1].D != eng.pipe.unet.ctx_dim:
             raise RuntimeError("text encoder widths do not add up to the UNet cross_attention_dim")
 

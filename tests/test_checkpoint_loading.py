@@ -291,6 +291,14 @@ def test_sdxl_worker_runs_from_single_file(tmp_path, monkeypatch):
     monkeypatch.setenv("MODEL_ROOT", str(tmp_path))
     monkeypatch.setenv("MODEL", "sdxl.safetensors")
     monkeypatch.delenv("LCM_HIP_SYNTHETIC", raising=False)
+    # a single-file checkpoint carries no vocabulary: real text-encoder weights without one are refused, never hash-tokenised
+    monkeypatch.delenv("LCM_TOKENIZER_DIR", raising=False)
+    with pytest.raises(RuntimeError, match="LCM_TOKENIZER_DIR"):
+        worker_factory.create_hip_worker(worker_id=5)
+    import tinytok
+    tinytok.write(str(tmp_path / "vocab" / "tokenizer"))
+    tinytok.write(str(tmp_path / "vocab" / "tokenizer_2"), pad="!")
+    monkeypatch.setenv("LCM_TOKENIZER_DIR", str(tmp_path / "vocab"))
     w = worker_factory.create_hip_worker(worker_id=5)
     try:
         assert type(w).__name__ == "HipLcmSDXLWorker"

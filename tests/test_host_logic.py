@@ -203,6 +203,57 @@ def test_png_parallel_deflate_is_one_valid_zlib_stream():
             os.environ["LCM_PNG_THREADS"] = old
 
 
+def test_bpe_tokenizer_id_contract(tmp_path):
+    """_BpeTokenizer against a vocabulary the test writes itself: BOS + BPE ids + EOS, padding to 77 with the directory's
+    own pad id (SD1.5 / first SDXL tokenizer: EOS; second SDXL tokenizer: id 0), truncation to 77 keeping EOS last, int32 --
+    the id contract of backends/rknnlcm.py:305-324."""
+    import torch
+    import tinytok
+    from sdlcm_amd.prompt import _BpeTokenizer
+    v = tinytok.vocab()
+    bos, eos = v["<|startoftext|>"], v["<|endoftext|>"]
+    t1 = _BpeTokenizer(tinytok.write(str(tmp_path / "tokenizer")))
+    ids = t1(["A cat, a dog", "cat " * 200, ""])
+    assert ids.dtype == torch.int32 and tuple(ids.shape) == (3, 77)
+    assert ids[0, :7].tolist() == [bos, v["a</w>"], v["cat</w>"], v[",</w>"], v["a</w>"], v["dog</w>"], eos]       # lower-cased, merged
+    assert (ids[0, 7:] == eos).all()
+    assert ids[1, 0] == bos and ids[1, 76] == eos and (ids[1, 1:76] == v["cat</w>"]).all()                       # truncated to 77
+    assert ids[2, 0] == bos and (ids[2, 1:] == eos).all()
+    t2 = _BpeTokenizer(tinytok.write(str(tmp_path / "tokenizer_2"), pad="!"))
+    ids2 = t2(["a cat"])
+    assert ids2.dtype == torch.int32 and ids2[0, :4].tolist() == [bos, v["a</w>"], v["cat</w>"], eos]
+    assert v["!"] == 0 and (ids2[0, 4:] == 0).all()                                                                  # SDXL tokenizer_2 pads with id 0
+
+
+def test_real_text_encoder_weights_need_a_vocabulary(tmp_path, monkeypatch):
+    """make_tokenizer: checkpoint directory first, then LCM_TOKENIZER_DIR; real weights without a vocabulary raise (never the
+    hashed stand-in); synthetic weights fall back to HashTokenizer."""
+    import tinytok
+    from sdlcm_amd.clip import HashTokenizer
+    from sdlcm_amd.lib import LcmHipError
+    from sdlcm_amd.prompt import _BpeTokenizer, make_tokenizer
+    monkeypatch.delenv("LCM_TOKENIZER_DIR", raising=False)
+    assert isinstance(make_tokenizer(None, "tokenizer", 49408, False), HashTokenizer)
+    with pytest.raises(LcmHipError, match="LCM_TOKENIZER_DIR"):
+        make_tokenizer(None, "tokenizer", 49408, True)
+    root = tmp_path / "ckpt"
+    (root / "tokenizer").mkdir(parents=True)                      # an empty directory is not a vocabulary
+    with pytest.raises(LcmHipError, match="no CLIP vocabulary"):
+        make_tokenizer(str(root), "tokenizer", 49408, True)
+    tinytok.write(str(root / "tokenizer"))
+    assert isinstance(make_tokenizer(str(root), "tokenizer", 49408, True), _BpeTokenizer)
+    env = tmp_path / "vocab"
+    tinytok.write(str(env / "tokenizer"))
+    tinytok.write(str(env / "tokenizer_2"), pad="!")
+    monkeypatch.setenv("LCM_TOKENIZER_DIR", str(env))
+    assert isinstance(make_tokenizer(None, "tokenizer", 49408, True), _BpeTokenizer)
+    assert int(make_tokenizer(None, "tokenizer_2", 49408, True)(["x"])[0, -1]) == 0
+    monkeypatch.setenv("LCM_TOKENIZER_DIR", str(env / "tokenizer"))           # the vocabulary files themselves: first tokenizer only
+    assert isinstance(make_tokenizer(None, "tokenizer", 49408, True), _BpeTokenizer)
+    with pytest.raises(LcmHipError):
+        make_tokenizer(None, "tokenizer_2", 49408, True)
+
+
 def test_hash_tokenizer_layout():
     from sdlcm_amd.clip import HashTokenizer, clip_param_spec
     from sdlcm_amd import weights
