@@ -68,16 +68,13 @@ def roofline_leg(pipe, P, guidance, ms_per_step):
     pair; avg = elapsed / launches.  achieved = sum of algorithmic FLOP of those launches / elapsed."""
     import torch
     from sdlcm_amd import ops
-    ops.PROFILE, ops.RECORD = [], []
-    with torch.cuda.stream(pipe.stream):
+    with torch.cuda.stream(pipe.stream), ops.profiling() as recs, ops.recording() as closures:
         for _ in range(max(2, int((150.0 + 120.0 * P.B) / max(ms_per_step, 1e-3)) + 1)):
             P.graph.launch()
         ops.profile_begin()
         pipe._enqueue(P, guidance)
         pipe.stream.synchronize()
         times = ops.profile_end()
-    recs, closures = ops.PROFILE, ops.RECORD
-    ops.PROFILE = ops.RECORD = None
     assert len(recs) == len(times) == len(closures), (len(recs), len(times), len(closures))
     agg = {}
     for r, (name, ms), c in zip(recs, times, closures):

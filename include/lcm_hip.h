@@ -216,7 +216,7 @@ int lcm_layernorm_f16(const void* x, const void* gamma, const void* beta, void* 
 /* ---- fused attention softmax(scale*Q K^T) V (Attention in BasicTransformerBlock.attn1/attn2) ----
  * Q: rows b*Sq+s, element (h*d + i) at Q[row*ldq + ...]; K,V likewise with Sk rows per batch; out [B*Sq][ldo].
  * d in {40, 64, 80, 160} (UNet / CLIP heads: 32x32x16-MFMA kernel, O for the whole head in registers) or, without causal
- * mask, d in {256, 512} (AutoencoderKL mid-block attention, one head of 512: 16x16x32-MFMA kernel, 16 query rows per wave,
+ * mask, d = 512 (AutoencoderKL mid-block attention, one head of 512: 16x16x32-MFMA kernel, 16 query rows per wave,
  * V^T fragments by ds_read_b64_tr_b16).  Online softmax in fp32, no S x S matrix in memory; a query row's result does not
  * depend on B or on the other rows.
  */

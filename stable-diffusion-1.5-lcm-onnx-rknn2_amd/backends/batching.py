@@ -39,6 +39,9 @@ class MicroBatcher:
         # beats batching (two batch-1 passes overlap to ~1.4x the time of one), with more waiting the first lane's next
         # batched pass is the better use of the GPU (batch 4 / 8 passes already fill it; two of them just share it)
         self.lane_max_waiting = 2
+        self._lane0_busy = False                    # lane 0 is inside run_batch (a pass, a first-use tune / capture, a style wait)
+        self._lane0_since = 0.0
+        self.lane0_stall_s = 0.25                   # ... for longer than this: the other lanes stop deferring to it
         self.sizes = sorted(s for s in set(int(x) for x in sizes) if 1 <= s <= max(1, int(max_batch))) or [1]
         self.max_batch = self.sizes[-1]
         self.window = max(0.0, float(window_ms)) / 1e3
@@ -56,7 +59,7 @@ class MicroBatcher:
             if self._closed:
                 raise RuntimeError("MicroBatcher is closed")
             self._q.append((key, item, fut, time.monotonic()))
-            self._cv.notify()
+            self._cv.notify_all()                   # every lane re-evaluates (a single notify may wake a lane that defers)
         return fut
 
     def _take(self):
@@ -77,8 +80,13 @@ class MicroBatcher:
                 if not self._q and self._closed:
                     return
                 if lane > 0 and len(self._q) > self.lane_max_waiting and not self._closed:
-                    self._cv.wait(0.002)            # high load: leave the queue to lane 0's next (larger) batch
-                    continue
+                    # high load: leave the queue to lane 0's next (larger) batch -- unless lane 0 is stuck inside one call
+                    # (multi-second first-use tune / graph capture, waiting for a style re-merge): then serve.  Woken by
+                    # lane 0's notify when it comes back for work, not by polling.
+                    stalled = self._lane0_busy and time.monotonic() - self._lane0_since > self.lane0_stall_s
+                    if not stalled:
+                        self._cv.wait(self.lane0_stall_s)
+                        continue
                 if self.window > 0:
                     head_key, deadline = self._q[0][0], self._q[0][3] + self.window
                     while (sum(1 for e in self._q if e[0] == head_key) < self.max_batch and not self._closed):
@@ -87,9 +95,17 @@ class MicroBatcher:
                             break
                         self._cv.wait(left)
                 key, batch = self._take()
+                if lane == 0:
+                    self._lane0_busy, self._lane0_since = True, time.monotonic()
             items = [e[1] for e in batch]
             try:
-                results = self.run_batch(key, items, lane) if self.lanes > 1 else self.run_batch(key, items)
+                try:
+                    results = self.run_batch(key, items, lane) if self.lanes > 1 else self.run_batch(key, items)
+                finally:
+                    if lane == 0:
+                        with self._cv:
+                            self._lane0_busy = False
+                            self._cv.notify_all()     # the other lanes re-evaluate their gate
                 if len(results) != len(items):
                     raise RuntimeError(f"run_batch returned {len(results)} results for {len(items)} items")
                 self.batches.append(len(items))

@@ -397,8 +397,13 @@ class HipLcmWorker:
                 print(f"[hip] FAILED to load style LoRA {sid}: {e!r}")
 
     def _apply_style(self, style_id, level):
-        with self._engine._style_cv:
-            self._engine.apply_style(style_id, level)
+        """The reference's hook (backends/cuda_worker.py:149-196).  The merged weights are shared by every lane, so -- like
+        ``_enter_style`` -- the re-merge waits until no pass is in flight: weights are never rewritten under a running graph."""
+        eng = self._engine
+        with eng._style_cv:
+            while eng._style_users > 0 and eng._want_style(style_id, level) != eng.active_style:
+                eng._style_cv.wait()
+            eng.apply_style(style_id, level)
 
     # ---- family hooks (operate on the engine: no worker object is ever captured by shared state) ----------------------
     def _synthetic_weights(self):

@@ -521,7 +521,9 @@ class VAEDecoderHip(_Net):
         a = "decoder.mid_block.attentions.0"
         self._put("attn.norm.g", sd[a + ".group_norm.weight"])
         self._put("attn.norm.b", sd[a + ".group_norm.bias"])
-        self.flash_attn = VAE_FLASH_ATTN and boc[-1] in (256, 512)
+        # the wide-head flash kernel is instantiated for d = 512 (every SD1.5 / SDXL AutoencoderKL); other widths take the
+        # GEMM -> softmax -> transpose -> GEMM form
+        self.flash_attn = VAE_FLASH_ATTN and boc[-1] == 512
         if self.flash_attn:
             self._put("attn.qkv.w", torch.cat([sd[f"{a}.{n}.weight"].reshape(boc[-1], boc[-1]) for n in ("to_q", "to_k", "to_v")], 0))
             self._put("attn.qkv.b", torch.cat([sd[f"{a}.{n}.bias"] for n in ("to_q", "to_k", "to_v")], 0))

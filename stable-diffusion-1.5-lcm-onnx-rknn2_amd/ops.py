@@ -18,9 +18,45 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-# Optional live per-launch timing (bench.py's roofline leg): when PROFILE is a list, every contraction /
-# attention launch is bracketed by HIP events recorded on the stream the kernel runs on.
-PROFILE = None
+# Launch hooks.  Both are THREAD-LOCAL: the lanes of a pipeline run on threads of their own (backends/hip_worker.py), and a
+# process-global hook let the eager launches of another lane (its prompt encoder runs outside the plan lock) land in the
+# tuning lane's record list -- the autotuner then replayed them on live buffers of a request in flight.
+#   recording():  every contraction / attention launch of THIS thread appends (plan key, metadata, replay closure)
+#   profiling():  every such launch appends the record of its algorithmic work (bench.py's roofline leg pairs them, in
+#                 launch order, with the library's event brackets: lcm_profile_begin / lcm_profile_end)
+import contextlib
+import threading
+
+_hooks = threading.local()
+
+
+def _record_list():
+    return getattr(_hooks, "record", None)
+
+
+def _profile_list():
+    return getattr(_hooks, "profile", None)
+
+
+@contextlib.contextmanager
+def recording():
+    """``with ops.recording() as recs:`` -- launches issued by this thread inside the block are appended to ``recs``."""
+    prev, recs = _record_list(), []
+    _hooks.record = recs
+    try:
+        yield recs
+    finally:
+        _hooks.record = prev
+
+
+@contextlib.contextmanager
+def profiling():
+    prev, recs = _profile_list(), []
+    _hooks.profile = recs
+    try:
+        yield recs
+    finally:
+        _hooks.profile = prev
 
 
 class _Timed:
@@ -29,7 +65,7 @@ class _Timed:
 
     def __init__(self, kind, tile, flops, bytes_):
         self.rec = None
-        if PROFILE is not None:
+        if _profile_list() is not None:
             self.rec = dict(kind=kind, flops=float(flops), bytes=float(bytes_))
 
     def __enter__(self):
@@ -37,12 +73,10 @@ class _Timed:
 
     def __exit__(self, *a):
         if self.rec is not None:
-            PROFILE.append(self.rec)
+            pl = _profile_list()
+            if pl is not None:
+                pl.append(self.rec)
         return False
-
-
-# Autotuner hook: when RECORD is a list, every contraction launch appends (plan key, replay closure).
-RECORD = None
 
 
 def plan_set(kind, M, N, K, aux, bm, bn, splits, variant=-1):
@@ -111,6 +145,7 @@ def gemm(a, w, out, *, bias=None, res=None, rowadd=None, rows_per_batch=0, a2=No
     N = w.shape[0] if N is None else N
     lda = a.stride(-2) if lda is None else lda
     ldo = out.stride(-2) if ldo is None else ldo
+    RECORD = _record_list()
     if RECORD is not None:
         kw = dict(bias=bias, res=res, rowadd=rowadd, rows_per_batch=rows_per_batch, a2=a2, epilogue=epilogue,
                   out_scale=out_scale, M=M, N=N, K=K, lda=lda, ldo=ldo, batch=batch, strideA=strideA, strideW=strideW,
@@ -118,7 +153,7 @@ def gemm(a, w, out, *, bias=None, res=None, rowadd=None, rows_per_batch=0, a2=No
         RECORD.append(((0, M, N, K, batch), dict(halo=False, geglu=(epilogue == 1), m_img=(img_rows if img_rows and M % img_rows == 0 else M),
                                                  splittable=(epilogue == 0 and batch == 1 and not (strideA or strideW or strideO))),
                        lambda: gemm(a, w, out, **kw)))
-    with _Timed("gemm", tile_config(M, N, batch) if PROFILE is not None else "", 2.0 * M * N * K * batch,
+    with _Timed("gemm", tile_config(M, N, batch) if _profile_list() is not None else "", 2.0 * M * N * K * batch,
                 2.0 * batch * (M * K + N * K + M * N)):
         rc = L.lcm_gemm_f16(_p(a), lda, _p(a2), a2.stride(0) if a2 is not None else 0, K1, _p(w), _p(bias), _p(rowadd),
                             rowadd.stride(0) if rowadd is not None else 0, rows_per_batch,
@@ -137,6 +172,7 @@ def gemm_ln(a, w, ln_g, ln_c, out, *, eps=1e-5, epilogue=0, img_rows=0):
     L = _lib.load()
     M, K = a.shape
     N = w.shape[0]
+    RECORD = _record_list()
     if RECORD is not None:
         RECORD.append(((0, M, N, K, 1), dict(halo=False, geglu=(epilogue == 1), m_img=(img_rows if img_rows and M % img_rows == 0 else M),
                                              splittable=False),
@@ -169,12 +205,13 @@ def conv3x3(x, w, out, B, H, W, Cin, Cout, *, bias=None, rowadd=None, res=None, 
         Ho, Wo = out_hw
     Mo = B * Ho * Wo
     taps = 4 if ups == 2 else 9                 # ups=2: phase-packed weights (packing.pack_conv3x3_up2), 4 taps per output
+    RECORD = _record_list()
     if RECORD is not None:
         kw = dict(bias=bias, rowadd=rowadd, res=res, stride=stride, ups=ups, stats=stats, out_hw=out_hw)
         key = (1, Mo, Cout, 9 * Cin, 1) if stride == 2 else (2, Mo, Cout, taps * Cin, (Wo << 1))
         RECORD.append((key, dict(halo=stride == 1, W=(W if ups == 2 else Wo), phases=4 if ups == 2 else 1, m_img=Mo // B, splittable=True),
                        lambda: conv3x3(x, w, out, B, H, W, Cin, Cout, **kw)))
-    with _Timed("conv3x3", tile_config(Mo, Cout) if PROFILE is not None else "", 2.0 * Mo * Cout * taps * Cin,
+    with _Timed("conv3x3", tile_config(Mo, Cout) if _profile_list() is not None else "", 2.0 * Mo * Cout * taps * Cin,
                 2.0 * (B * H * W * Cin + 9 * Cin * Cout + Mo * Cout)):
         rc = L.lcm_conv3x3_f16(_p(x), _p(w), _p(bias), _p(rowadd), rowadd.stride(0) if rowadd is not None else 0,
                                _p(res), _p(out), B, H, W, Cin, Cout, stride, flags, sbuf, sbytes,
@@ -193,6 +230,7 @@ def conv3x3_gn(x, w, out, B, H, W, C1, Cout, *, x2=None, C2=0, gn_scale=None, gn
     Cin = C1 + (C2 if x2 is not None else 0)
     Ho, Wo = (2 * H, 2 * W) if ups else (H, W)
     Mo = B * Ho * Wo
+    RECORD = _record_list()
     if RECORD is not None:
         kw = dict(x2=x2, C2=C2, gn_scale=gn_scale, gn_shift=gn_shift, silu=silu, bias=bias, rowadd=rowadd, res=res, ups=ups,
                   stats=stats)
@@ -296,6 +334,7 @@ def embed_tokens(ids, tok_emb, pos_emb, out, B, S, D):
 def attention(q, k, v, out, B, heads, Sq, Sk, d, *, ldq, ldk, ldv, ldo, scale=None, causal=False):
     L = _lib.load()
     scale = d ** -0.5 if scale is None else scale
+    RECORD = _record_list()
     if RECORD is not None:
         RECORD.append((None, None, lambda: attention(q, k, v, out, B, heads, Sq, Sk, d, ldq=ldq, ldk=ldk, ldv=ldv, ldo=ldo,
                                                      scale=scale, causal=causal)))

@@ -52,20 +52,23 @@ def draw_noise(seed: int, h: int, w: int, n_extra: int, sigma: float = 1.0):
     return lat, extra
 
 
-_WS = {}
+_DEFAULT_WS = {}
 
 
-def _splitk_workspace(device, lane=0, mb=None):
-    key = (device.type, device.index if device.index is not None else torch.cuda.current_device(), lane)
-    t = _WS.get(key)
-    if t is None and mb is not None:
-        t = _WS[key] = torch.empty(int(mb) << 18, dtype=torch.float32, device=device)
+def _default_workspace(device):
+    """The device-wide split-K workspace of launches outside any pipeline lane (eager launches of tests / tools on foreign
+    streams): one process-lifetime tensor per device, never a lane's."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    t = _DEFAULT_WS.get(key)
     if t is None:
-        # sized for a batch of 8 at 768x768 (472 MB) / SDXL 1024x1024 (fp32 [splits][M][N] of the largest split layer); a launch
-        # that needs more fails loudly (a silently smaller split factor would change the numbers)
-        t = torch.empty(int(os.environ.get("LCM_SPLITK_WS_MB", "1024")) << 18, dtype=torch.float32, device=device)
-        _WS[key] = t
+        t = _DEFAULT_WS[key] = torch.empty(int(os.environ.get("LCM_SPLITK_DEFAULT_WS_MB", "256")) << 18, dtype=torch.float32, device=device)
     return t
+
+
+def _new_workspace(device, mb=None):
+    # sized for a batch of 8 at 768x768 (472 MB) / SDXL 1024x1024 (fp32 [splits][M][N] of the largest split layer); a launch
+    # that needs more fails loudly (a silently smaller split factor would change the numbers)
+    return torch.empty(int(mb if mb is not None else os.environ.get("LCM_SPLITK_WS_MB", "1024")) << 18, dtype=torch.float32, device=device)
 
 
 class _Lane:
@@ -79,14 +82,16 @@ class _Lane:
         self.unet, self.vae = unet, vae
         self.stream = torch.cuda.Stream(device=pipe.device)
         self.plans = {}
-        # The library keeps raw workspace pointers (per stream / per device): the tensors are process-lifetime singletons
-        # per (device, lane) and outlive every pipeline / captured graph that may still launch with them.
-        self.splitk_ws = _splitk_workspace(pipe.device, index)
+        # The split-K workspace belongs to THIS lane of THIS pipeline (the library looks it up by launch stream): two
+        # pipelines on one GPU -- an SD1.5 and an SDXL engine, or unshared engines of several pool workers -- run on threads
+        # with no common lock and must never share fp32 slabs.  It lives as long as the lane (i.e. as the captured graphs that
+        # bake its pointer in) and is unregistered by LcmHipPipeline.close().
+        self.splitk_ws = _new_workspace(pipe.device)
         ops.set_stream_workspace(self.stream, self.splitk_ws)
         # side stream: launches that fork off the main chain inside one pass (the resnets' conv_shortcut GEMMs), with a
         # split-K workspace of its own -- they run concurrently with the main stream's split layers
         self.side = torch.cuda.Stream(device=pipe.device)
-        self.side_ws = _splitk_workspace(pipe.device, ("side", index), mb=256)
+        self.side_ws = _new_workspace(pipe.device, mb=256)
         ops.set_stream_workspace(self.side, self.side_ws)
         self.unet.side_stream = self.side
         self.vae.side_stream = self.side
@@ -145,10 +150,10 @@ class LcmHipPipeline:
         self.lanes = [_Lane(self, 0, self.unet, self.vae)]
         self.stream = self.lanes[0].stream
         self._plans = self.lanes[0].plans
-        # fp32 scratch for deterministic split-K of the deep-K / small-M layers (low-res UNet levels at batch 1):
-        # lane 0's is also the device-wide default (eager launches on other streams, e.g. tests).
+        # fp32 scratch for deterministic split-K of the deep-K / small-M layers (low-res UNet levels at batch 1): per lane
+        # (above); launches on streams that are no lane's (tests, tools) use a device-wide default that no lane shares.
         self._splitk_ws = self.lanes[0].splitk_ws
-        ops.set_workspace(self._splitk_ws)
+        ops.set_workspace(_default_workspace(self.device))
         if "LCM_CONV_IMPL" in os.environ:            # A/B switches for kernel work
             ops.set_conv_impl(int(os.environ["LCM_CONV_IMPL"]))
         if "LCM_GN_FUSED_BYTES" in os.environ:
@@ -218,11 +223,8 @@ class LcmHipPipeline:
         stream = P.lane.stream
         with self._build_lock, torch.cuda.stream(stream):
             self._enqueue(P, 1.0)                    # allocate scratch, warm caches
-            ops.RECORD = []
-            try:
+            with ops.recording() as recs:            # thread-local: another lane's eager launches never land in here
                 self._enqueue(P, 1.0)
-            finally:
-                recs, ops.RECORD = ops.RECORD, None
             stream.synchronize()
             todo = [r for r in recs if r[0] is not None and r[0] not in self._tuned_keys]
             # in situ every layer's weights come from HBM and its input was written by the previous kernel, never by a
@@ -242,6 +244,28 @@ class LcmHipPipeline:
                 if P.graph is not None:
                     P.graph.close()
             L.plans.clear()
+
+    def close(self):
+        """Drop the captured graphs and take this pipeline's workspaces out of the library's per-stream table (the library
+        keeps raw pointers).  Idempotent; also run when the pipeline is collected."""
+        lanes, self.lanes = getattr(self, "lanes", []), []
+        for L in lanes:
+            for P in L.plans.values():
+                if P.graph is not None:
+                    P.graph.close()
+            L.plans.clear()
+            try:
+                torch.cuda.synchronize(self.device)
+                ops.set_stream_workspace(L.stream, None)
+                ops.set_stream_workspace(L.side, None)
+            except Exception:
+                pass
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     # ------------------------------------------------------------------------------------------
     @torch.inference_mode()
@@ -310,7 +334,7 @@ class LcmHipPipeline:
             # ---- the sampler: eager once (allocates scratch), then captured + replayed ----
             eager = (not self.use_graph) or taps is not None or want_float
             if eager:
-                with self._build_lock:               # eager launches allocate scratch and read ops.RECORD / PROFILE
+                with self._build_lock:               # eager launches allocate scratch
                     final = self._enqueue(P, guidance_scale, want_float=want_float, taps=taps)
             else:
                 if P.graph is None:

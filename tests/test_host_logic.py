@@ -254,6 +254,20 @@ def test_real_text_encoder_weights_need_a_vocabulary(tmp_path, monkeypatch):
         make_tokenizer(None, "tokenizer_2", 49408, True)
 
 
+def test_launch_hooks_are_thread_local():
+    import threading
+    from sdlcm_amd import ops
+    seen = []
+    with ops.recording() as recs, ops.profiling() as prof:
+        assert ops._record_list() is recs and ops._profile_list() is prof
+        t = threading.Thread(target=lambda: seen.append((ops._record_list(), ops._profile_list())))
+        t.start(); t.join()
+        with ops.recording() as inner:             # nesting restores the outer list
+            assert ops._record_list() is inner
+        assert ops._record_list() is recs
+    assert seen == [(None, None)] and ops._record_list() is None and ops._profile_list() is None
+
+
 def test_hash_tokenizer_layout():
     from sdlcm_amd.clip import HashTokenizer, clip_param_spec
     from sdlcm_amd import weights
@@ -361,6 +375,34 @@ def test_microbatcher_errors_reach_every_waiter_and_window():
         with pytest.raises(ValueError):
             f.result(5)
     assert mb.submit("k", 3).result(5) == 3                 # the dispatcher survives a failed pass
+    mb.close()
+
+
+def test_second_lane_serves_when_lane0_is_stuck():
+    """Lanes above 0 leave a long queue to lane 0's next (larger) batch -- but only while lane 0 actually comes back for it: when
+    lane 0 sits inside one call for long (first-use tune / graph capture, style wait) the second lane takes the work."""
+    import threading, time
+    from sdlcm_amd.backends.batching import MicroBatcher
+    gate, served = threading.Event(), []
+
+    def run(key, items, lane):
+        if key == "stuck":
+            gate.wait(10)
+        served.append((lane, key, len(items), time.monotonic()))
+        return list(items)
+
+    mb = MicroBatcher(run, max_batch=8, lanes=2)
+    mb.lane0_stall_s = 0.1
+    t0 = time.monotonic()
+    first = mb.submit("stuck", 0)
+    time.sleep(0.05)
+    if not mb._lane0_busy:                       # lane 1 happened to take the stuck job: nothing to show on this run
+        gate.set(); first.result(5); mb.close(); return
+    futs = [mb.submit("a", i) for i in range(6)]  # more than lane_max_waiting: lane 1 defers at first ...
+    assert [f.result(5) for f in futs] == list(range(6))            # ... and serves once lane 0 has been away > lane0_stall_s
+    assert all(lane == 1 for lane, key, n, t in served if key == "a") and time.monotonic() - t0 < 3.0
+    gate.set()
+    assert first.result(5) == 0
     mb.close()
 
 

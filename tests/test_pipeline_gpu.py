@@ -274,6 +274,55 @@ def test_two_lanes_in_flight_match_solo_runs(state):
         assert np.array_equal(rgb, solo[i]["rgb"]) and np.array_equal(lat, solo[i]["latents"]), (lane, rep, i)
 
 
+def test_tuning_record_hook_is_thread_local(state):
+    """The autotuner's record hook only sees launches of the thread that opened it (round 2: a process-global hook collected the
+    eager prompt-encoder launches of the other lane, and the tuner replayed them on that lane's live buffers -- in-place
+    residual GEMMs accumulated).  While one thread records a sampler pass on lane 1, another encodes prompts eagerly on lane 0:
+    no text-encoder shape (K = 768 with 77-row images) reaches the record list, the encoder outputs stay bit-identical, and
+    the other thread's own hook state is untouched."""
+    import threading
+    from sdlcm_amd import ops
+    from sdlcm_amd.clip import ClipTextHip, synthetic_clip
+    hip = state["hip"]
+    enc = ClipTextHip(synthetic_clip(), None, device=hip.device)
+    ids = torch.randint(1, 49000, (2, 77), dtype=torch.int32)
+    s0 = torch.cuda.Stream(device=hip.device)
+    with torch.cuda.stream(s0):
+        ref = enc.forward(ids).clone()
+        s0.synchronize()
+    stop, outs, seen, errs = threading.Event(), [], [], []
+
+    def encode_loop():
+        try:
+            with torch.cuda.stream(s0):
+                while not stop.is_set():
+                    seen.append(ops._record_list())
+                    outs.append(enc.forward(ids).clone())
+                s0.synchronize()
+        except BaseException as e:      # noqa
+            errs.append(e)
+    P = hip.plan(1, 16, 16, 2, lane=1)
+    th = threading.Thread(target=encode_loop)
+    with torch.cuda.stream(P.lane.stream):
+        hip._enqueue(P, 1.0)                       # allocates this plan's scratch
+        th.start()
+        with ops.recording() as recs:
+            for _ in range(3):
+                hip._enqueue(P, 1.0)
+        P.lane.stream.synchronize()
+    stop.set()
+    th.join()
+    assert not errs, errs
+    assert len(outs) >= 1 and all(r is None for r in seen)
+    assert ops._record_list() is None
+    keys = [r[0] for r in recs if r[0] is not None]
+    assert keys and not any(k[0] == 0 and k[3] == 768 and k[1] % 77 == 0 and k[2] != hip.unet.kv_total for k in keys), "text-encoder launches leaked into the record"
+    n_pass = len([r for r in recs])
+    assert n_pass % 3 == 0                          # three identical passes, nothing else
+    for o in outs:
+        assert torch.equal(o, ref)
+
+
 def test_graphs_of_earlier_plans_survive_larger_plans(state):
     """A captured hipGraph bakes raw pointers in.  Building and running a batch-8 plan (bigger GroupNorm workspaces, scratch,
     statistics buffers) after a batch-1 plan must not free or move anything the batch-1 graph still uses: the batch-1
