@@ -200,9 +200,18 @@ def main():
     backend = os.environ.get("LCM_BENCH_BACKEND", "gloo" if one_dev else "nccl")      # RCCL refuses two ranks on one device
     if one_dev:
         local = 0
-    if world > 1:
+    # LCM_BENCH_FORCE_DIST=1: initialise the process group at world size 1 too, so that the RCCL code path of the N > 1 leg
+    # (init_process_group("nccl", device_id=...), GPU-tensor broadcast / all_gather / all_reduce) loads and executes on a
+    # one-GPU box -- the rehearsal of everything but the xGMI hop itself
+    force_dist = os.environ.get("LCM_BENCH_FORCE_DIST", "0") == "1"
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         torch.cuda.set_device(local)
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
@@ -223,47 +232,66 @@ def main():
     D = pipe.unet.ctx_dim
 
     bcast_ms = {}
+    encoders = {}
 
-    def prime(Bx, lane=0):
-        """Fill a plan's resident inputs: embeddings broadcast from rank 0 over RCCL, per-request noise."""
-        P = pipe.plan(Bx, h, w, n, lane=lane)
+    def prompt_embeddings(pl, count):
+        """What north_star describes: the rank that owns the prompt encoder (rank 0) runs it -- ClipTextHip on the HIP kernels,
+        synthetic CLIP weights of the UNet's context width, hashed token ids of fixed prompts -- for ALL `count` requests of
+        the job; the other ranks receive the result by broadcast."""
+        from sdlcm_amd.clip import CLIP_BIGG, CLIP_L, ClipTextHip, HashTokenizer, synthetic_clip
+        enc = encoders.get(id(pl))
+        if enc is None:
+            Dx = pl.unet.ctx_dim
+            cfgs = [(CLIP_L, 2), (CLIP_BIGG, 3)] if Dx == 2048 else \
+                   [(dict(CLIP_L, hidden_size=Dx, num_attention_heads=Dx // 64, intermediate_size=4 * Dx), 2)]
+            enc = encoders[id(pl)] = [ClipTextHip(synthetic_clip(c, seed=sd), c, device=pl.device) for c, sd in cfgs]
+        prompts = [f"benchmark prompt number {i} a lighthouse at dusk" for i in range(count)]
+        outs = []
+        for e in enc:
+            ids = HashTokenizer(e.cfg["vocab_size"])(prompts)
+            outs.append(e.forward(ids, output="penultimate") if len(enc) > 1 else e.forward(ids))
+        return torch.cat(outs, dim=-1) if len(outs) > 1 else outs[0]
+
+    def prime(Bx, lane=0, pl=None, hh=None, ww=None, nn=None):
+        """Fill a plan's resident inputs: embeddings from rank 0's prompt encoder, broadcast over RCCL; per-request noise."""
+        pl = pl or pipe
+        hh, ww, nn = hh or h, ww or w, nn or n
+        P = pl.plan(Bx, hh, ww, nn, lane=lane)
         with torch.cuda.stream(P.lane.stream):
-            allpe = torch.empty(world * Bx, 77, D, dtype=torch.float16, device=dev)
-            if rank == 0:
-                allpe.copy_(torch.randn(world * Bx, 77, D, generator=torch.Generator().manual_seed(1)).half())
+            allpe = prompt_embeddings(pl, world * Bx) if rank == 0 else None
             if dist is not None:
+                from sdlcm_amd.distributed import broadcast_embeddings
                 P.lane.stream.synchronize()
                 for rep in range(2):                  # first call sets the communicator up; the second is the exchange itself
                     dist.barrier()
                     torch.cuda.synchronize()
                     tb = time.perf_counter()
-                    if backend == "nccl":
-                        dist.broadcast(allpe, src=0)      # the one exchange step: 118 KB per prompt over xGMI
+                    if backend == "nccl":             # the one exchange step: 118 KB per prompt over xGMI
+                        got = broadcast_embeddings(allpe, world * Bx, 77, pl.unet.ctx_dim, dev)
                     else:
-                        host = allpe.cpu()
-                        dist.broadcast(host, src=0)
-                        allpe.copy_(host)
+                        got = broadcast_embeddings(allpe.cpu() if allpe is not None else None, world * Bx, 77, pl.unet.ctx_dim, "cpu").to(dev)
                     torch.cuda.synchronize()
                     bcast_ms[Bx] = (time.perf_counter() - tb) * 1e3
-            P.ehs.copy_(allpe[rank * Bx:(rank + 1) * Bx].reshape(Bx * 77, D))
-            if pipe.unet.has_added:      # SDXL: pooled text embedding + size/crop ids
+                allpe = got
+            P.ehs.copy_(allpe[rank * Bx:(rank + 1) * Bx].reshape(Bx * 77, pl.unet.ctx_dim))
+            if pl.unet.has_added:      # SDXL: pooled text embedding + size/crop ids
                 from sdlcm_amd.pipeline import sinusoid_host
-                pooled = torch.randn(Bx, pipe.unet.added_dim - 6 * 256, generator=torch.Generator().manual_seed(2))
-                tid = torch.from_numpy(sinusoid_host(np.array([S, S, 0, 0, S, S] * Bx, np.float32), 256)).reshape(Bx, -1)
+                pooled = torch.randn(Bx, pl.unet.added_dim - 6 * 256, generator=torch.Generator().manual_seed(2))
+                tid = torch.from_numpy(sinusoid_host(np.array([8 * hh, 8 * ww, 0, 0, 8 * hh, 8 * ww] * Bx, np.float32), 256)).reshape(Bx, -1)
                 P.add_in.copy_(torch.cat([pooled, tid], 1).half())
             for b in range(Bx):
-                l0, extra = draw_noise(1000 + rank * Bx + b, h, w, n - 1)
+                l0, extra = draw_noise(1000 + rank * Bx + b, hh, ww, nn - 1)
                 P.lat0[b].copy_(l0[0])
                 for i, e in enumerate(extra):
                     P.noise[i, b].copy_(e[0])
             P.wemb.copy_(torch.from_numpy(guidance_scale_embedding(np.zeros(Bx, np.float32), P.wemb.shape[1])).half())
-            pipe.tune(P)                               # per-shape launch autotune (once)
-            pipe._enqueue(P, 1.0)                      # eager warm-up: allocates scratch
+            pl.tune(P)                                 # per-shape launch autotune (once)
+            pl._enqueue(P, 1.0)                        # eager warm-up: allocates scratch
             P.lane.stream.synchronize()
             from sdlcm_amd import ops
             g = ops.Graph()
             with g:
-                pipe._enqueue(P, 1.0)
+                pl._enqueue(P, 1.0)
             P.graph = g
         return P
 
@@ -284,7 +312,7 @@ def main():
         return time.perf_counter() - t0, K * len(Ps)
 
     def timed(P, K, W):
-        with torch.cuda.stream(pipe.stream):
+        with torch.cuda.stream(P.lane.stream):
             for _ in range(W):
                 P.graph.launch()
             torch.cuda.synchronize()
@@ -327,9 +355,26 @@ def main():
                    "batch_per_gpu": B, "global_batch": world * B, "image": f"{S}x{S}", "lcm_steps": n,
                    "parallelism": f"independent requests x{world} (RCCL broadcast of prompt embeddings only)"},
     }
-    if world > 1:
-        line["exchange"] = {"what": f"broadcast of [{world * B},77,{D}] fp16 prompt embeddings from rank 0, before the timed region",
-                            "backend": "rccl" if backend == "nccl" else backend, "ms": round(bcast_ms.get(B, 0.0), 3)}
+    if dist is not None:
+        line["exchange"] = {"what": f"broadcast of [{world * B},77,{D}] fp16 prompt embeddings (rank 0's ClipTextHip output) before the "
+                                    f"timed region; all_gather / all_reduce(MAX) of the per-rank times",
+                            "backend": "rccl" if backend == "nccl" else backend, "ms": round(bcast_ms.get(B, 0.0), 3),
+                            "world_size": world}
+        # one real sharded generation through the same exchange code (distributed.run_sharded): every rank generates its shard
+        # of 2 * world requests with pipe.generate, RGB8 gathered on rank 0 (outside the timed region; a functional check)
+        from sdlcm_amd.distributed import run_sharded
+        cdev = torch.device(dev if backend == "nccl" else "cpu")
+        nreq = 2 * world
+        pe_all = prompt_embeddings(pipe, nreq) if rank == 0 else None
+        if pe_all is not None and backend != "nccl":
+            pe_all = pe_all.cpu()
+
+        def _gen(pe, seeds):
+            out = pipe.generate(pe, seeds, 64, 64, 2, 1.0)
+            return torch.from_numpy(out["rgb"]).to(cdev)
+        full = run_sharded(_gen, pe_all, [5000 + i for i in range(nreq)], cdev, gather_to=0)
+        if rank == 0:
+            line["exchange"]["sharded_check"] = {"requests": nreq, "gathered": list(full.shape), "ok": bool(full.shape[0] == nreq and full.any())}
     if rank == 0 and world == 1 and not args.no_roofline:
         line["roofline"] = roofline_leg(pipe, P, 1.0, dt / args.steps * 1e3)
         if args.model == "sdxl":
@@ -351,8 +396,36 @@ def main():
             line["extra_two_lanes"] = {"images_per_s": round(npass / dtl, 2), "ms_per_image_per_lane": round(dtl / args.steps * 1e3, 2),
                                        "workload": "same batch-1 requests, two in flight on two lanes of the pipeline (own stream / scratch / "
                                                    "graph / split-K workspace, shared weights); never `value`"}
+        if not args.no_extra and B == 1 and args.model == "sd15" and S == 512:
+            # BASELINE configs[3]: 768x768, 8 steps, batch 8 on one GPU (3 timed passes)
+            P3 = prime(8, hh=96, ww=96, nn=8)
+            dt3, _ = timed(P3, 3, 1)
+            fl3 = 5.74e12 * (768 * 768) / (512 * 512) * 8 / 4
+            line["extra_768_b8"] = {"images_per_s": round(8 * 3 / dt3, 3), "ms_per_step": round(dt3 / 3 * 1e3, 2),
+                                    "pipeline_tflops": round(22.95e12 * 8 / (dt3 / 3) / 1e12, 1),
+                                    "workload": "SD1.5 LCM 768x768, 8 steps, batch 8 (BASELINE configs[3]; 22.95 TFLOP per image, SURVEY 8d)"}
+            del fl3
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(host_threads())
+        if not args.no_extra and B == 1 and args.model == "sd15" and S == 512 and os.environ.get("LCM_BENCH_SDXL", "1") != "0":
+            # BASELINE configs[4]: SDXL-base architecture, 1024x1024, 30 steps, batch 1, guidance 1.0 (no CFG), 2 timed passes.
+            # Its own pipeline (2.6 G synthetic parameters); the SD1.5 one is released first.
+            pipe.close()
+            encoders.clear()
+            import gc
+            gc.collect(); torch.cuda.empty_cache()
+            from sdlcm_amd.config import SDXL_UNET, unet_config, vae_config
+            ucfg, vcfg = unet_config(SDXL_UNET), vae_config(dict(scaling_factor=0.13025, sample_size=1024, force_upcast=True))
+            xl = LcmHipPipeline(weights.synthetic_state_dict(weights.unet_param_spec(ucfg), 0),
+                                weights.synthetic_state_dict(weights.vae_param_spec(vcfg), 1), ucfg, vcfg, device=dev)
+            Px = prime(1, pl=xl, hh=128, ww=128, nn=30)
+            dtx, _ = timed(Px, 2, 1)
+            flx = 6.761e12 * 30 + 10.470e12
+            line["extra_sdxl"] = {"images_per_s": round(2 / dtx, 4), "ms_per_step": round(dtx / 2 * 1e3, 1),
+                                  "pipeline_tflops": round(flx / (dtx / 2) / 1e12, 1),
+                                  "workload": "SDXL-base architecture 1024x1024, 30 steps, batch 1, guidance 1.0 (no CFG: UNet batch 1), fp16 "
+                                              "VAE with residual-stream rescaling (BASELINE configs[4]; 213 TFLOP per image, SURVEY 8d)"}
+            xl.close()
     if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:

@@ -290,9 +290,10 @@ class HipLcmWorker:
             # reference's fp32 pipeline (the parity tests compare against an fp32 oracle)
             print(f"[hip] CUDA_DTYPE={dtype_str}: the HIP backend computes with fp16 operands / fp32 accumulation "
                   f"(max |delta| vs the fp32 reference pipeline < 1e-2 on the decoded image)")
-        device = (os.environ.get("HIP_DEVICE") or os.environ.get("CUDA_DEVICE") or "cuda:0").strip()
         if not torch.cuda.is_available():
             raise LcmHipError("HipLcmWorker needs an MI355X; no CPU fallback exists on this path")
+        from .worker_factory import pick_device
+        device = pick_device(worker_id, torch.cuda.device_count())      # LCM_DEVICES=all: worker i -> GPU i mod N
         share = os.environ.get("LCM_SHARE_ENGINE", "1").lower() not in ("0", "false", "no", "off")
         from .styles import STYLE_REGISTRY
         ekey = (self.FAMILY, device, "synthetic" if synthetic else os.path.join(model_root, model_name),

@@ -39,6 +39,31 @@ def detect_worker_type() -> str:
     raise RuntimeError(f"Unknown cross_attention_dim={cad}")
 
 
+def pick_device(worker_id: int, device_count: int, env=None) -> str:
+    """Which GPU worker ``worker_id`` runs on.  The reference maps worker i to accelerator core i mod N
+    (server/lcm_sr_server.py:140-152 for the NPU cores; one CUDA device otherwise, backends/cuda_worker.py:53): with
+    ``LCM_DEVICES=all`` worker i takes ``cuda:{i % device_count}``, with ``LCM_DEVICES=0,2,5`` the i-th entry of that list
+    (cyclically); without it every worker takes HIP_DEVICE / CUDA_DEVICE / cuda:0 as before (workers on one GPU share one
+    resident engine).  Pure function of its arguments."""
+    env = os.environ if env is None else env
+    spec = (env.get("LCM_DEVICES") or "").strip().lower()
+    if spec:
+        if device_count <= 0:
+            raise RuntimeError("LCM_DEVICES is set but no GPU is visible")
+        if spec == "all":
+            ids = list(range(device_count))
+        else:
+            try:
+                ids = [int(x) for x in spec.replace(";", ",").split(",") if x.strip() != ""]
+            except ValueError:
+                raise RuntimeError(f"LCM_DEVICES={spec!r}: expected 'all' or a comma-separated list of device indices")
+            bad = [i for i in ids if i < 0 or i >= device_count]
+            if bad or not ids:
+                raise RuntimeError(f"LCM_DEVICES={spec!r}: device indices {bad or ids} outside the {device_count} visible GPUs")
+        return f"cuda:{ids[int(worker_id) % len(ids)]}"
+    return (env.get("HIP_DEVICE") or env.get("CUDA_DEVICE") or "cuda:0").strip()
+
+
 def create_hip_worker(worker_id: int):
     kind = detect_worker_type()
     from .hip_worker import HipLcmSDXLWorker, HipLcmWorker

@@ -378,6 +378,22 @@ def test_microbatcher_errors_reach_every_waiter_and_window():
     mb.close()
 
 
+def test_workers_map_to_devices_like_the_reference_maps_npu_cores():
+    """LCM_DEVICES=all: worker i -> cuda:(i mod N), the reference's rule for its accelerator cores
+    (server/lcm_sr_server.py:140-152); a list picks from the list; unset keeps the single-device behaviour."""
+    from sdlcm_amd.backends.worker_factory import pick_device
+    assert [pick_device(i, 8, {"LCM_DEVICES": "all"}) for i in range(10)] == [f"cuda:{i % 8}" for i in range(10)]
+    assert [pick_device(i, 8, {"LCM_DEVICES": "1,3,6"}) for i in range(4)] == ["cuda:1", "cuda:3", "cuda:6", "cuda:1"]
+    assert pick_device(5, 8, {}) == "cuda:0" and pick_device(5, 8, {"CUDA_DEVICE": "cuda:2"}) == "cuda:2"
+    assert pick_device(5, 8, {"HIP_DEVICE": "cuda:4", "CUDA_DEVICE": "cuda:2"}) == "cuda:4"
+    assert pick_device(3, 1, {"LCM_DEVICES": "all"}) == "cuda:0"
+    for bad in ("9", "0,x", "-1"):
+        with pytest.raises(RuntimeError, match="LCM_DEVICES"):
+            pick_device(0, 8, {"LCM_DEVICES": bad})
+    with pytest.raises(RuntimeError, match="no GPU"):
+        pick_device(0, 0, {"LCM_DEVICES": "all"})
+
+
 def test_second_lane_serves_when_lane0_is_stuck():
     """Lanes above 0 leave a long queue to lane 0's next (larger) batch -- but only while lane 0 actually comes back for it: when
     lane 0 sits inside one call for long (first-use tune / graph capture, style wait) the second lane takes the work."""
