@@ -65,3 +65,33 @@ def latents_blob(lat: np.ndarray) -> bytes:
     t = torch.as_tensor(np.asarray(lat, dtype=np.float32))
     l8 = torch.nn.functional.adaptive_avg_pool2d(t, (8, 8)).to(torch.float16).contiguous()
     return l8.numpy().astype(np.float16, copy=False).tobytes(order="C")
+
+
+def latent_to_nchw(x) -> np.ndarray:
+    """Latents in any of the layouts the NPU runtime may hand back -> numpy NCHW (backends/rknn_worker.py:182-220): 4-D only;
+    axis 1 of size 4 is taken as channels, else a last axis of size 4 (NHWC), else the first axis of size 4 moves to position 1.
+    Pinned by tests/golden/worker_contract.npz (recorded from the reference)."""
+    if x is None:
+        raise ValueError("latent is None")
+    if hasattr(x, "detach") and hasattr(x, "cpu") and hasattr(x, "numpy"):
+        x = x.detach().cpu().numpy()
+    x = np.asarray(x)
+    if x.ndim != 4:
+        raise ValueError(f"latent must be 4D, got shape={x.shape}")
+    if x.shape[1] == 4:
+        return x
+    if x.shape[-1] == 4:
+        return np.transpose(x, (0, 3, 1, 2))
+    if 4 in x.shape:
+        c = list(x.shape).index(4)
+        axes = [a for a in range(4) if a != c]
+        axes.insert(1, c)
+        return np.transpose(x, axes)
+    raise ValueError(f"cannot interpret latent layout, shape={x.shape}")
+
+
+def check_size(width: int, height: int) -> None:
+    """The size rule of the pipeline's check_inputs (backends/rknnlcm.py:380-381): both sides divisible by 8."""
+    if height % 8 != 0 or width % 8 != 0:
+        raise ValueError(f"`height` and `width` have to be divisible by 8 but are {height} and {width}.")
+

@@ -253,7 +253,7 @@ class _Engine:
         try:
             pipe, self.pipe = self.pipe, None
             if pipe is not None:
-                pipe.drop_plans()
+                pipe.close()                          # graphs dropped, split-K workspaces unregistered
             self.encode, self.enc, self.tok, self.styles, self.active_style = None, [], [], {}, None
             self.lane_encoders = {}
         finally:

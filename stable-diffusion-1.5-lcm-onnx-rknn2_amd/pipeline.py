@@ -44,6 +44,13 @@ def sinusoid_host(values: np.ndarray, dim: int) -> np.ndarray:
     return np.concatenate([np.cos(e), np.sin(e)], axis=1).astype(np.float32)
 
 
+def check_size(width: int, height: int) -> None:
+    """What diffusers' check_inputs raises for the reference ("`height` and `width` have to be divisible by 8 ...";
+    backends/rknnlcm.py:380-381 has the same rule and text), as an LcmHipError; pinned by tests/golden/worker_contract.json."""
+    if width % 8 or height % 8 or width <= 0 or height <= 0:
+        raise LcmHipError(f"`height` and `width` have to be divisible by 8 but are {height} and {width}.")
+
+
 def draw_noise(seed: int, h: int, w: int, n_extra: int, sigma: float = 1.0):
     g = torch.Generator(device="cpu").manual_seed(int(seed))
     shape = (1, 4, h, w)
@@ -280,10 +287,7 @@ class LcmHipPipeline:
         torch.cuda.set_device(self.device)        # the pool may call from a thread other than the constructing one
         pe = torch.as_tensor(prompt_embeds)
         B = pe.shape[0]
-        if width % 8 or height % 8 or width <= 0 or height <= 0:
-            # what diffusers' check_inputs raises for the reference ("`height` and `width` have to be divisible by 8");
-            # backends/rknnlcm.py:380-381 has the same rule
-            raise LcmHipError(f"`height` and `width` have to be divisible by 8 but are {height} and {width}.")
+        check_size(width, height)
         h, w = height // VAE_SCALE_FACTOR, width // VAE_SCALE_FACTOR
         steps = int(steps)
         has_cond = self.unet.has_cond

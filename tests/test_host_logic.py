@@ -378,6 +378,89 @@ def test_microbatcher_errors_reach_every_waiter_and_window():
     mb.close()
 
 
+def test_run_job_reproduces_the_reference_recordings():
+    """HipLcmWorker.run_job against what DiffusersCudaWorker.run_job did with a recording fake ``pipe``
+    (tests/golden/worker_contract.json, recorded from the reference by tests/golden/make_contract_golden.py): the values the
+    sampler receives (prompt, width, height, steps, guidance -- with the reference's int() / float() coercions), the seed policy
+    (request seed returned as is; none: a draw below 10^8), the style in effect DURING the pass (the adapter and weight the
+    reference's _apply_style handed to the pipeline, after its level clamp; off for level 0 / unknown styles), no style state
+    bleeding into the next job, and the error text of malformed sizes.  The engine is a recording stand-in: no GPU involved."""
+    import json
+    import types
+    import numpy as np
+    from sdlcm_amd.backends import hip_worker
+    from sdlcm_amd.backends.styles import STYLE_REGISTRY
+    from sdlcm_amd.pipeline import check_size
+    from sdlcm_amd.lib import LcmHipError
+    doc = json.load(open(os.path.join(ROOT, "tests", "golden", "worker_contract.json")))
+    passes = []
+
+    class FakeEngine:
+        batcher, batch_sizes = None, (1,)
+        pipe = types.SimpleNamespace(sched=types.SimpleNamespace(init_noise_sigma=1.0))
+        styles = {sid: object() for sid in STYLE_REGISTRY}                 # every registered style "loaded", as in the recording
+        _want_style = hip_worker._Engine._want_style
+
+        def run_batch(self, key, items):
+            passes.append((key, items))
+            return [(np.zeros((8, 8, 3), np.uint8), np.zeros((1, 4, 8, 8), np.float16)) for _ in items]
+
+    w = object.__new__(hip_worker.HipLcmWorker)
+    w.worker_id, w._engine = 0, FakeEngine()
+    adapter_to_style = {sd.adapter_name: sid for sid, sd in STYLE_REGISTRY.items()}
+    for rec in doc["run_job"]:
+        r = dict(rec["request"])
+        sl = r.pop("style_lora", None)
+        req = types.SimpleNamespace(**r)
+        if sl is not None:
+            req.style_lora = types.SimpleNamespace(style=sl[0], level=sl[1])
+        del passes[:]
+        if "error" in rec:
+            with pytest.raises(RuntimeError) as ei:
+                w.run_job(types.SimpleNamespace(req=req))
+            assert str(ei.value) == rec["error"] and not passes
+            continue
+        png, seed = w.run_job(types.SimpleNamespace(req=req))
+        assert png[:8] == b"\x89PNG\r\n\x1a\n" and rec["png_magic_ok"]
+        ref_pipe = [e for e in rec["events"] if e[0] == "pipe"][0][1]
+        (key, items), = passes
+        width, height, steps, guidance, style_id, level = key
+        assert (width, height, steps, guidance) == (ref_pipe["width"], ref_pipe["height"], ref_pipe["num_inference_steps"], ref_pipe["guidance_scale"])
+        assert items[0][0].prompt == ref_pipe["prompt"]
+        if rec["seed_is_request_seed"]:
+            assert seed == rec["returned_seed"] == ref_pipe["generator_initial_seed"] and items[0][1] == seed
+        else:
+            assert 0 <= seed < doc["seed_policy_without_seed"]["upper_bound_exclusive"] and items[0][1] == seed
+        # the style in effect during the pass: what the reference's _apply_style handed to the pipeline before the call
+        before = rec["events"][0]
+        want = w._engine._want_style(style_id, level)
+        if before[0] == "set_adapters":
+            assert want is not None and [want[0]] == [adapter_to_style[a] for a in before[1]] and [want[1]] == before[2]
+        else:
+            assert before == ["disable_lora"] and want is None
+        assert rec["events"][-1] == ["disable_lora"]         # reference: reset after every job; here the NEXT job's key carries its own style
+    # no bleed: a styled job followed by a plain one -> the plain job's pass asks for no style
+    del passes[:]
+    w.run_job(types.SimpleNamespace(req=types.SimpleNamespace(prompt="s", size="64x64", num_inference_steps=1, guidance_scale=1.0, seed=1,
+                                                                style_lora=types.SimpleNamespace(style="papercut", level=2))))
+    w.run_job(types.SimpleNamespace(req=types.SimpleNamespace(prompt="p", size="64x64", num_inference_steps=1, guidance_scale=1.0, seed=2)))
+    assert w._engine._want_style(*passes[0][0][4:]) is not None and w._engine._want_style(*passes[1][0][4:]) is None
+    # the pipeline's size rule (check_inputs): accept / reject and the message text
+    n = 0
+    for rec in doc["check_inputs"]:
+        a = rec["args"]
+        if not (a.get("prompt") == "a" and a.get("callback_steps") == 1 and len(a) == 4):
+            continue
+        n += 1
+        if rec["outcome"] == "ok":
+            check_size(a["width"], a["height"])
+        else:
+            with pytest.raises(LcmHipError) as ei:
+                check_size(a["width"], a["height"])
+            assert str(ei.value) == rec["error"]
+    assert n >= 4
+
+
 def test_workers_map_to_devices_like_the_reference_maps_npu_cores():
     """LCM_DEVICES=all: worker i -> cuda:(i mod N), the reference's rule for its accelerator cores
     (server/lcm_sr_server.py:140-152); a list picks from the list; unset keeps the single-device behaviour."""
