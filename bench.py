@@ -106,6 +106,7 @@ def roofline_leg(pipe, P, guidance, ms_per_step):
             "method": "dominant instantiation replayed back-to-back on its real per-layer operands inside one HIP event pair",
             "mfma_flop_per_pass": round(tot_f), "by_kernel": table}
     out["algorithmic_bytes_per_launch_avg"] = round(dom["bytes"] / dom["n"])     # operands + result, each counted once
+    out.update(_pmc_counters(name.replace(" +splitk", "")))
     out["traffic_unit"] = "bytes per launch (fabric reads + writes)"
     out["traffic_source"] = traffic_src
     out["kernel_launches_per_pass"] = len(times)
@@ -113,6 +114,27 @@ def roofline_leg(pipe, P, guidance, ms_per_step):
 
 
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
+PMC_SUMMARY_FILE = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")
+
+
+def _pmc_counters(kernel_name):
+    """MFMA-busy fraction and HBM GB/s of the dominant kernel from the committed rocprofv3 --pmc passes over an eager
+    single-kernel target of the same shape class (profiles/r03_pmc_summary.json <- tools/pmc_round3.sh + tools/pmc_summary.py;
+    counters cannot be read from inside this process).  Absent kernel: the fields are null and the reason is given."""
+    import json
+    try:
+        with open(PMC_SUMMARY_FILE) as f:
+            tab = json.load(f)
+    except Exception as e:
+        return {"mfma_busy_frac": None, "hbm_gbs": None, "pmc_source": f"{os.path.relpath(PMC_SUMMARY_FILE, ROOT)} unreadable ({e!r})"}
+    key = kernel_name.rstrip(">").strip()
+    for k, v in tab.items():
+        if k.rstrip(">").strip().startswith(key):
+            return {"mfma_busy_frac": v["mfma_busy_frac"], "hbm_gbs": v["hbm_gbs"], "effective_clock_ghz": v["effective_clock_ghz"],
+                    "pmc_source": f"{v['source']} ({v['what']}): SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs over GRBM_GUI_ACTIVE / 8 XCDs; "
+                                  f"(2 x FETCH_SIZE + WRITE_SIZE) / kernel time"}
+    return {"mfma_busy_frac": None, "hbm_gbs": None,
+            "pmc_source": f"kernel '{kernel_name}' is not in {os.path.relpath(PMC_SUMMARY_FILE, ROOT)} (has {sorted(tab)}): run tools/pmc_round3.sh"}
 
 
 def _pmc_traffic(kernel_name, batch):

@@ -4,11 +4,39 @@ tests/test_sdxl_worker.py:230-256: 512, 768, 1024), against the CPU oracle on id
 Tolerance: north_star -- per-pixel |delta| < 1e-2 on the decoded image in [0,1].  Parity tests come first in the
 file; self-comparison (determinism) checks last, so a parity regression is never masked by them.
 The oracle restates diffusers' published algorithm (parity unpinned at that boundary: oracle/__init__.py)."""
+import os
+
 import numpy as np
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+
+# The oracle outputs of the BASELINE-size cases are committed fixtures (tests/golden/oracle_*.npz, computed by
+# tests/golden/make_oracle_golden.py in the build container: final latents + the decoded image on a stride-4 pixel grid):
+# minutes of CPU oracle time per run otherwise (round 2: 718 s of the driver's 900 s limit).  LCM_LIVE_ORACLE=1 runs the
+# oracle live on the full image instead.  Small sizes keep a live oracle run (tests/test_pipeline_gpu.py).
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _golden(case):
+    p = os.path.join(GOLD, f"oracle_{case}.npz")
+    if os.environ.get("LCM_LIVE_ORACLE", "0") == "1" or not os.path.exists(p):
+        return None
+    return np.load(p)
+
+
+def _err_vs(out, gold, ref_fn, req=0):
+    """max |delta| of the decoded [0,1] image of request ``req`` against the fixture's grid, or against a live oracle run."""
+    img = out["image"][req:req + 1].transpose(0, 3, 1, 2)
+    if gold is not None:
+        st = int(gold["stride"])
+        e = np.abs(_img01(img[0][:, ::st, ::st]) - _img01(gold["image_grid"].astype(np.float32)))
+        u8 = np.abs(out["rgb"][req][::st, ::st].astype(int) - gold["u8_grid"].astype(int)).max()
+        return e, int(u8)
+    ref = ref_fn()
+    e = np.abs(_img01(img) - _img01(ref["image"]))
+    return e, int(np.abs(out["rgb"][req:req + 1].astype(int) - ref["image_u8"].astype(int)).max())
 
 
 def _embeds(B, D=768, seed=5):
@@ -26,8 +54,14 @@ def sd15():
     from oracle.pipeline import LCMPipelineOracle
     usd, vsd = weights.synthetic_unet(), weights.synthetic_vae()
     hip = LcmHipPipeline(usd, vsd, device="cuda:0")
-    yield dict(hip=hip, ora=LCMPipelineOracle(usd, vsd))
-    hip.drop_plans()
+    cache = {}
+
+    def ora():                     # built only when a case has no fixture (or LCM_LIVE_ORACLE=1)
+        if "o" not in cache:
+            cache["o"] = LCMPipelineOracle(usd, vsd)
+        return cache["o"]
+    yield dict(hip=hip, ora=ora)
+    hip.close()
 
 
 def test_config1_512_4step_batch1_parity(sd15):
@@ -35,12 +69,11 @@ def test_config1_512_4step_batch1_parity(sd15):
     same request is bit-identical to the eager pass."""
     hip, ora = sd15["hip"], sd15["ora"]
     pe = _embeds(1, seed=42)
-    ref = ora(pe.float(), 512, 512, 4, 1.0, 42)
     out = hip.generate(pe, [42], 512, 512, 4, 1.0, want_float=True)
-    e = np.abs(_img01(out["image"].transpose(0, 3, 1, 2)) - _img01(ref["image"]))
-    print(f"[parity] 512x512 4-step batch 1: max|d|={e.max():.4g} mean|d|={e.mean():.3g}")
+    e, u8 = _err_vs(out, _golden("sd15_512_4step"), lambda: ora()(pe.float(), 512, 512, 4, 1.0, 42))
+    print(f"[parity] 512x512 4-step batch 1: max|d|={e.max():.4g} mean|d|={e.mean():.3g} u8 max diff {u8}")
     assert e.max() < 1e-2
-    assert np.abs(out["rgb"].astype(int) - ref["image_u8"].astype(int)).max() <= 3
+    assert u8 <= 3
     rep = hip.generate(pe, [42], 512, 512, 4, 1.0)
     assert np.array_equal(rep["rgb"], out["rgb"]) and np.array_equal(rep["latents"], out["latents"])
 
@@ -54,8 +87,7 @@ def test_config2_512_batch8_parity_per_request(sd15):
     seeds = [500 + i for i in range(B)]
     out = hip.generate(pe, seeds, 512, 512, 1, 1.0, want_float=True)
     for i in (0, 7):
-        ref = ora(pe[i:i + 1].float(), 512, 512, 1, 1.0, seeds[i])
-        e = np.abs(_img01(out["image"][i:i + 1].transpose(0, 3, 1, 2)) - _img01(ref["image"]))
+        e, _ = _err_vs(out, _golden(f"sd15_512_b8_1step_req{i}"), lambda: ora()(pe[i:i + 1].float(), 512, 512, 1, 1.0, seeds[i]), req=i)
         print(f"[parity] 512x512 batch 8, request {i}: max|d|={e.max():.4g}")
         assert e.max() < 1e-2
     graph = hip.generate(pe, seeds, 512, 512, 1, 1.0)
@@ -71,10 +103,9 @@ def test_config3_768_8step_parity(sd15):
     backends/cuda_worker.py:91) on both sides; the S = 9216 self-attention is the long-sequence case."""
     hip, ora = sd15["hip"], sd15["ora"]
     pe = _embeds(1, seed=9)
-    ref = ora(pe.float(), 768, 768, 8, 1.0, 31)
     out = hip.generate(pe, [31], 768, 768, 8, 1.0, want_float=True)
     assert out["rgb"].shape == (1, 768, 768, 3)
-    e = np.abs(_img01(out["image"].transpose(0, 3, 1, 2)) - _img01(ref["image"]))
+    e, _ = _err_vs(out, _golden("sd15_768_8step"), lambda: ora()(pe.float(), 768, 768, 8, 1.0, 31))
     print(f"[parity] 768x768 8-step: max|d|={e.max():.4g} mean|d|={e.mean():.3g}")
     assert e.max() < 1e-2
 
@@ -90,8 +121,14 @@ def sdxl():
     usd = weights.synthetic_state_dict(weights.unet_param_spec(ucfg), 0)
     vsd = weights.synthetic_state_dict(weights.vae_param_spec(vcfg), 1)
     hip = LcmHipPipeline(usd, vsd, ucfg, vcfg, device="cuda:0")
-    yield dict(hip=hip, ora=LCMPipelineOracle(usd, vsd, ucfg, vcfg))
-    hip.drop_plans()
+    cache = {}
+
+    def ora():
+        if "o" not in cache:
+            cache["o"] = LCMPipelineOracle(usd, vsd, ucfg, vcfg)
+        return cache["o"]
+    yield dict(hip=hip, ora=ora)
+    hip.close()
 
 
 def _sdxl_inputs():
@@ -116,10 +153,9 @@ def test_config4_sdxl_1024_parity(sdxl, guidance, steps):
     if guidance > 1:
         kw.update(negative_embeds=torch.zeros_like(pe), negative_added=(torch.zeros_like(pooled), tids))
         okw.update(negative_embeds=torch.zeros_like(pe).float(), negative_added=(torch.zeros_like(pooled).float(), tids))
-    ref = ora(pe.float(), 1024, 1024, steps, guidance, 21, **okw)
     out = hip.generate(pe, [21], 1024, 1024, steps, guidance, want_float=True, **kw)
     assert out["rgb"].shape == (1, 1024, 1024, 3)
-    e = np.abs(_img01(out["image"].transpose(0, 3, 1, 2)) - _img01(ref["image"]))
+    e, _ = _err_vs(out, _golden(f"sdxl_1024_g{int(guidance)}_{steps}step"), lambda: ora()(pe.float(), 1024, 1024, steps, guidance, 21, **okw))
     print(f"[parity] SDXL 1024x1024 g={guidance} {steps}-step: max|d|={e.max():.4g} mean|d|={e.mean():.3g}")
     assert e.max() < 1e-2
     rep = hip.generate(pe, [21], 1024, 1024, steps, guidance, **kw)             # captured graph == the eager pass

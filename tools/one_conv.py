@@ -11,6 +11,12 @@ ops.set_kernel_variant(variant)
 x = torch.randn(B * H * H, Cin, device="cuda", dtype=torch.float16)
 w = torch.randn(Cout, 9 * Cin, device="cuda", dtype=torch.float16)
 o = torch.empty(B * H * H, Cout, device="cuda", dtype=torch.float16)
+gn = len(sys.argv) > 6 and sys.argv[6] == "gn"       # GroupNorm-fused form (scale / shift tables applied while staging the halo)
+if gn:
+    sc, sh = torch.rand(B, Cin, device="cuda") + 0.5, torch.randn(B, Cin, device="cuda") * 0.1
 for _ in range(5):
-    ops.conv3x3(x, w, o, B, H, H, Cin, Cout)
+    if gn:
+        ops.conv3x3_gn(x, w, o, B, H, H, Cin, Cout, gn_scale=sc, gn_shift=sh, silu=True)
+    else:
+        ops.conv3x3(x, w, o, B, H, H, Cin, Cout)
 torch.cuda.synchronize()
