@@ -42,14 +42,20 @@ __device__ __forceinline__ float silu_f(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
 }
 // exact-GELU 0.5 x (1 + erf(x/sqrt2)) with erf from Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below the fp16
-// output rounding): one v_rcp + one v_exp + a degree-5 Horner instead of libm erff (~4x fewer VALU in the GEGLU epilogue)
+// output rounding), arranged for the VALU (the GEGLU epilogue of ff.net.0 is VALU-issue-bound: ~3500 of the ~4900 issue
+// cycles of a 128x128 tile are this function):  with z = |x|/sqrt2, t = 1/(1 + p z), erf(z) = 1 - poly(t) e^{-z^2},
+//   gelu(x) = 0.5 x + 0.5 |x| erf(z) = max(x, 0) - |x| * [0.5 poly(t)] * 2^(-x^2 * 0.5 log2 e)
+// one v_rcp + one v_exp + 5 FMAs + 5 other VALU = 14 issue slots (the textbook arrangement took 20).
 __device__ __forceinline__ float gelu_erf_f(float x) {
-    const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
-    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const float erf_abs = 1.0f - poly * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);
-    const float erfv = copysignf(erf_abs, x);
-    return 0.5f * x * (1.0f + erfv);
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(ax, 0.3275911f * 0.70710678118654752f, 1.0f));
+    float poly = __builtin_fmaf(t, 0.5f * 1.061405429f, 0.5f * -1.453152027f);
+    poly = __builtin_fmaf(t, poly, 0.5f * 1.421413741f);
+    poly = __builtin_fmaf(t, poly, 0.5f * -0.284496736f);
+    poly = __builtin_fmaf(t, poly, 0.5f * 0.254829592f);
+    poly *= t;
+    const float e = __builtin_amdgcn_exp2f((x * x) * -0.72134752044448170f);        // 2^(-x^2/2 * log2 e)
+    return __builtin_fmaf(-ax, poly * e, fmaxf(x, 0.0f));
 }
 
 // Sums over the 16 lanes of a DPP row (lanes 16g .. 16g+15) of eight values at once, results in every lane of the row: the

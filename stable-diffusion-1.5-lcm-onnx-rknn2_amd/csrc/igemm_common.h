@@ -217,8 +217,13 @@ row16_sum8(ssum, ssq);
                     }
                 }
                 h4 o;
+                if (ln_mu) {          // the folded LayerNorm's constants already carry the bias (lcm_gemm_ln_f16 takes none)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = (half_t)((x[j] + bx[j]) * gelu_erf_f(g[j] + bg[j]));
+                    for (int j = 0; j < 4; ++j) o[j] = (half_t)(x[j] * gelu_erf_f(g[j]));
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = (half_t)((x[j] + bx[j]) * gelu_erf_f(g[j] + bg[j]));
+                }
                 *reinterpret_cast<h4*>(outb + (long long)m * p.ldo + nout) = o;
             }
         }
