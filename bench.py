@@ -113,7 +113,7 @@ def roofline_leg(pipe, P, guidance, ms_per_step):
     return out
 
 
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic.json")
 PMC_SUMMARY_FILE = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")
 
 
@@ -138,7 +138,7 @@ def _pmc_counters(kernel_name):
 
 
 def _pmc_traffic(kernel_name, batch):
-    """HBM-side bytes per launch of `kernel_name`, from the committed PMC passes (profiles/r02_traffic.json: rocprofv3 --pmc
+    """HBM-side bytes per launch of `kernel_name`, from the committed PMC passes (profiles/r03_traffic.json: rocprofv3 --pmc
     FETCH_SIZE and WRITE_SIZE in separate runs over one eager pass of this workload, tools/pmc_pass.sh; counters cannot be
     read from inside bench.py).  FETCH_SIZE x2 is the gfx950 correction of MI355X_MICROARCH.md's HBM section.  When the
     dominant kernel / batch is not in the file the value is None AND the reason is reported (`traffic_source`) and printed
