@@ -152,6 +152,10 @@ def _pmc_traffic(kernel_name, batch):
         print("[bench] WARNING: " + msg, file=sys.stderr)
         return None, msg
     e = tab.get(kernel_name)
+    if not e:          # rocprofv3 prints every template argument (defaulted ones too): match on the instantiation's prefix
+        key = kernel_name.rstrip(">").strip()
+        hits = [v for k, v in tab.items() if k.rstrip(">").strip().startswith(key)]
+        e = hits[0] if len(hits) == 1 else None
     if not e:
         msg = (f"dominant kernel '{kernel_name}' (batch {batch}) is absent from {os.path.relpath(TRAFFIC_FILE, ROOT)} "
                f"(has: {sorted(tab)[:6]}...): re-run tools/pmc_pass.sh")
