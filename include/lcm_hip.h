@@ -218,7 +218,8 @@ int lcm_layernorm_f16(const void* x, const void* gamma, const void* beta, void* 
  * d in {40, 64, 80, 160} (UNet / CLIP heads: 32x32x16-MFMA kernel, O for the whole head in registers) or, without causal
  * mask, d = 512 (AutoencoderKL mid-block attention, one head of 512: 16x16x32-MFMA kernel, 16 query rows per wave,
  * V^T fragments by ds_read_b64_tr_b16).  Online softmax in fp32, no S x S matrix in memory; a query row's result does not
- * depend on B or on the other rows.
+ * depend on B or on the other rows.  scale > 0: the softmax scale (diffusers: d^-0.5).  scale <= 0: Q already carries
+ * scale * log2(e) (the caller folded both into the projection that produced Q) and the logits are used as they are.
  */
 int lcm_attention_f16(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* out, int ldo,
                       int B, int heads, int Sq, int Sk, int d, float scale, int causal, void* stream);

@@ -820,7 +820,7 @@ extern "C" int lcm_attention_f16(const void* Q, int ldq, const void* K, int ldk,
     LCM_REQUIRE(B > 0 && heads > 0 && Sq > 0 && Sk > 0, "attention: bad shape");
     LCM_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0, "attention: misaligned leading dims");
     AttnParams p = {(const half_t*)Q, (const half_t*)K, (const half_t*)V, (half_t*)out, ldq, ldk, ldv, ldo,
-                    B, heads, Sq, Sk, scale * 1.4426950408889634f, causal ? 1 : 0};
+                    B, heads, Sq, Sk, scale > 0.f ? scale * 1.4426950408889634f : 1.0f, causal ? 1 : 0};   // scale <= 0: Q arrives pre-scaled
     LCM_REQUIRE(!causal || Sq == Sk, "attention: causal mask needs Sq == Sk");
     hipStream_t s = (hipStream_t)stream;
     if (g_attn2 && !causal && Sk >= 128 && g_attn_waves != 2) {       // long (self-attention) sequences: the streaming kernel

@@ -115,13 +115,14 @@ class LoraStyle:
                 continue
             k, sub = re.match(r"^transformer_blocks\.(\d+)\.(.*)$", rest).groups()
             q, C = f"{p}.{k}", d.shape[0]
+            qs = getattr(unet, "qs", {}).get(q, 1.0)                         # to_q rows carry the softmax scale (model.Q_PRESCALE)
             if sub.startswith("attn1.to_") and sub[-1] in "qkv":
                 i = "qkv".index(sub[-1])
-                acc(q + ".qkv.w", (i * C, (i + 1) * C), *fold(q + ".qkv.w", d))
+                acc(q + ".qkv.w", (i * C, (i + 1) * C), *fold(q + ".qkv.w", d * qs if i == 0 else d))
             elif sub == "attn1.to_out.0":
                 acc(q + ".o1.w", (0, C), d)
             elif sub == "attn2.to_q":
-                acc(q + ".q2.w", (0, C), *fold(q + ".q2.w", d))
+                acc(q + ".q2.w", (0, C), *fold(q + ".q2.w", d * qs))
             elif sub in ("attn2.to_k", "attn2.to_v"):
                 off, Ck = unet.kv_off[q]
                 o = off + (Ck if sub.endswith("v") else 0)

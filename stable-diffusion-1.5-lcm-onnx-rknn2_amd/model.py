@@ -36,6 +36,8 @@ LN_FOLD = os.environ.get("LCM_LN_FOLD", "1") != "0"
 # the captured graph against 47.6 without -- a cross-stream edge costs more here than the ~10 us GEMM it takes off the chain.
 FORK_SHORTCUT = os.environ.get("LCM_FORK_SHORTCUT", "0") != "0"
 FUSE_GN_CONV = os.environ.get("LCM_FUSE_GN_CONV", "1") != "0"
+# softmax scale (and log2 e) folded into the to_q weights of the UNet's attention layers (see _pack_transformer)
+Q_PRESCALE = os.environ.get("LCM_Q_PRESCALE", "1") != "0"
 # AutoencoderKL mid-block attention (one head, d = 512) as ONE fused flash kernel behind one q|k|v GEMM; "0" = the round-1
 # GEMM -> softmax -> transpose -> GEMM form with its B x S x S score matrix in HBM (kept for comparison)
 VAE_FLASH_ATTN = os.environ.get("LCM_VAE_FLASH_ATTN", "1") != "0"
@@ -200,6 +202,7 @@ class UNetHip(_Net):
         self.temb_dim = boc[0] * 4
         nb = len(boc)
         temb_list, kv_list = [], []
+        self.qs = {}                                                     # per transformer block: the factor carried by its to_q rows
         self._put("conv_in.w", pack_conv3x3(sd["conv_in.weight"]))
         self._put("conv_in.b", sd["conv_in.bias"])
         for n in ("linear_1", "linear_2"):
@@ -218,20 +221,20 @@ class UNetHip(_Net):
             for j in range(cfg["layers_per_block"]):
                 self._pack_resnet(sd, f"down_blocks.{i}.resnets.{j}", temb_list)
                 if cfg["down_attn"][i]:
-                    self._pack_transformer(sd, f"down_blocks.{i}.attentions.{j}", kv_list, depth_at(cfg, i))
+                    self._pack_transformer(sd, f"down_blocks.{i}.attentions.{j}", kv_list, depth_at(cfg, i), heads_at(cfg, i))
             if i < nb - 1:
                 p = f"down_blocks.{i}.downsamplers.0.conv"
                 self._put(p + ".w", pack_conv3x3(sd[p + ".weight"]))
                 self._put(p + ".b", sd[p + ".bias"])
         self._pack_resnet(sd, "mid_block.resnets.0", temb_list)
-        self._pack_transformer(sd, "mid_block.attentions.0", kv_list, depth_at(cfg, nb - 1))
+        self._pack_transformer(sd, "mid_block.attentions.0", kv_list, depth_at(cfg, nb - 1), heads_at(cfg, nb - 1))
         self._pack_resnet(sd, "mid_block.resnets.1", temb_list)
         up_attn = tuple(reversed(cfg["down_attn"]))
         for i in range(nb):
             for j in range(cfg["layers_per_block"] + 1):
                 self._pack_resnet(sd, f"up_blocks.{i}.resnets.{j}", temb_list)
                 if up_attn[i]:
-                    self._pack_transformer(sd, f"up_blocks.{i}.attentions.{j}", kv_list, depth_at(cfg, nb - 1 - i))
+                    self._pack_transformer(sd, f"up_blocks.{i}.attentions.{j}", kv_list, depth_at(cfg, nb - 1 - i), heads_at(cfg, nb - 1 - i))
             if i < nb - 1:
                 p = f"up_blocks.{i}.upsamplers.0.conv"
                 self._put(p + ".w", (pack_conv3x3_up2 if UPS_PHASES else pack_conv3x3)(sd[p + ".weight"]))
@@ -276,7 +279,7 @@ class UNetHip(_Net):
         self._put(name + ".lnw", g32, torch.float32)
         self._put(name + ".lnb", b32, torch.float32)
 
-    def _pack_transformer(self, sd, p, kv_list, depth=1):
+    def _pack_transformer(self, sd, p, kv_list, depth=1, heads=8):
         self._put(p + ".norm.g", sd[p + ".norm.weight"])
         self._put(p + ".norm.b", sd[p + ".norm.bias"])
         self._put(p + ".proj_in.w", pack_conv1x1(sd[p + ".proj_in.weight"]))      # 1x1 conv (SD1.5) or Linear (SDXL)
@@ -288,8 +291,16 @@ class UNetHip(_Net):
             for n in ("norm1", "norm2", "norm3"):
                 self._put(f"{q}.{n}.g", sd[f"{t}.{n}.weight"])
                 self._put(f"{q}.{n}.b", sd[f"{t}.{n}.bias"])
-            wqkv = torch.cat([sd[f"{t}.attn1.to_{n}.weight"] for n in "qkv"], 0)
-            wq2, wff, bff = sd[f"{t}.attn2.to_q.weight"], sd[f"{t}.ff.net.0.proj.weight"], sd[f"{t}.ff.net.0.proj.bias"]
+            wqkv = torch.cat([sd[f"{t}.attn1.to_{n}.weight"] for n in "qkv"], 0).float()
+            wq2, wff, bff = sd[f"{t}.attn2.to_q.weight"].float(), sd[f"{t}.ff.net.0.proj.weight"], sd[f"{t}.ff.net.0.proj.bias"]
+            if Q_PRESCALE:
+                # softmax scale d^-0.5 and the exp2 conversion log2(e), multiplied into the (bias-free) to_q rows in fp32 before
+                # the one fp16 rounding of the weight: the attention kernels then take q as it comes out of the projection
+                # (no second fp16 rounding of a scaled copy, no per-element multiply); lora.LoraStyle scales its to_q deltas alike
+                C = wq2.shape[0]
+                self.qs[q] = qs = (C // heads) ** -0.5 * 1.4426950408889634
+                wqkv[:C] *= qs
+                wq2 = wq2 * qs
             if LN_FOLD:
                 self._put_ln_fold(q + ".qkv", wqkv, None, sd[f"{t}.norm1.weight"], sd[f"{t}.norm1.bias"])
                 self._put_ln_fold(q + ".q2", wq2, None, sd[f"{t}.norm2.weight"], sd[f"{t}.norm2.bias"])
@@ -371,7 +382,7 @@ class UNetHip(_Net):
                 ops.layernorm(h, w[q + ".norm1.g"], w[q + ".norm1.b"], n, M, C)
                 ops.gemm(n, w[q + ".qkv.w"], qkv, img_rows=HW)
             ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], a, B, heads, HW, HW, d, ldq=3 * C, ldk=3 * C,
-                          ldv=3 * C, ldo=C)
+                          ldv=3 * C, ldo=C, scale=0.0 if Q_PRESCALE else None)
             ops.gemm(a, w[q + ".o1.w"], h, bias=w[q + ".o1.b"], res=h, img_rows=HW)
             if LN_FOLD:
                 ops.gemm_ln(h, w[q + ".q2.w"], w[q + ".q2.g"], w[q + ".q2.c"], q2, img_rows=HW)
@@ -380,7 +391,7 @@ class UNetHip(_Net):
                 ops.gemm(n, w[q + ".q2.w"], q2, img_rows=HW)
             off, _ = self.kv_off[q]
             ops.attention(q2, kv_all[:, off:off + C], kv_all[:, off + C:off + 2 * C], a, B, heads, HW, TEXT_SEQ_LEN, d,
-                          ldq=C, ldk=self.kv_total, ldv=self.kv_total, ldo=C)
+                          ldq=C, ldk=self.kv_total, ldv=self.kv_total, ldo=C, scale=0.0 if Q_PRESCALE else None)
             ops.gemm(a, w[q + ".o2.w"], h, bias=w[q + ".o2.b"], res=h, img_rows=HW)
             if LN_FOLD:
                 ops.gemm_ln(h, w[q + ".ff1.w"], w[q + ".ff1.g"], w[q + ".ff1.c"], ff, epilogue=1, img_rows=HW)

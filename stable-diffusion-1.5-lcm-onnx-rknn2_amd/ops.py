@@ -332,6 +332,7 @@ def embed_tokens(ids, tok_emb, pos_emb, out, B, S, D):
 
 
 def attention(q, k, v, out, B, heads, Sq, Sk, d, *, ldq, ldk, ldv, ldo, scale=None, causal=False):
+    """scale None: d^-0.5.  scale 0: q already carries scale * log2(e) (folded into the projection that made it, model.Q_PRESCALE)."""
     L = _lib.load()
     scale = d ** -0.5 if scale is None else scale
     RECORD = _record_list()

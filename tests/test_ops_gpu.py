@@ -634,6 +634,20 @@ def test_attention_peaked_softmax():
     close(out, ref, rtol=6e-3, what="attention peaked")
 
 
+@pytest.mark.parametrize("heads,Sq,Sk,d", [(8, 1024, 1024, 40), (8, 256, 77, 80), (4, 64, 64, 160), (10, 300, 300, 64)])
+def test_attention_prescaled_q(heads, Sq, Sk, d):
+    """scale <= 0: q arrives with d^-0.5 * log2(e) already in it (model.Q_PRESCALE folds it into the to_q weights) -- the
+    streaming, the register-staged and the d = 160 kernels against torch SDPA in fp32 on the unscaled q."""
+    B, C = 2, heads * d
+    q, k, v = rnd(B * Sq, C, seed=1), rnd(B * Sk, C, seed=2), rnd(B * Sk, C, seed=3)
+    qh, kh, vh = (t.float().reshape(B, S, heads, d).transpose(1, 2) for t, S in ((q, Sq), (k, Sk), (v, Sk)))
+    ref = F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(B * Sq, C)
+    qs = (q.float() * (d ** -0.5 * 1.4426950408889634)).to(torch.float16)
+    out = torch.empty(B * Sq, C, dtype=torch.float16, device=DEV)
+    ops.attention(qs.to(DEV), k.to(DEV), v.to(DEV), out, B, heads, Sq, Sk, d, ldq=C, ldk=C, ldv=C, ldo=C, scale=0.0)
+    close(out, ref, rtol=6e-3, what=f"prescaled attention S{Sq}x{Sk} d{d}")
+
+
 def test_attention_strided_qkv():
     """Fused QKV buffer: q/k/v are column slices of one [B*S, 3C] tensor."""
     B, heads, S, d = 2, 8, 256, 40
