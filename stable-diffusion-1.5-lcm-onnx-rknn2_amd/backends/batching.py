@@ -79,6 +79,11 @@ class MicroBatcher:
                     self._cv.wait()
                 if not self._q and self._closed:
                     return
+                if lane > 0 and not self._lane0_busy and not self._closed:
+                    # lane 0 is idle and has been notified as well: the job is its to take.  A lone caller never touches
+                    # the other lanes (each owns ~1.3 GB of workspace, its own buffers, tune and graph capture on first use)
+                    self._cv.wait(0.05)
+                    continue
                 if lane > 0 and len(self._q) > self.lane_max_waiting and not self._closed:
                     # high load: leave the queue to lane 0's next (larger) batch -- unless lane 0 is stuck inside one call
                     # (multi-second first-use tune / graph capture, waiting for a style re-merge): then serve.  Woken by
@@ -97,6 +102,8 @@ class MicroBatcher:
                 key, batch = self._take()
                 if lane == 0:
                     self._lane0_busy, self._lane0_since = True, time.monotonic()
+                    if self._q and self.lanes > 1:
+                        self._cv.notify_all()         # what is left may now go to the other lanes
             items = [e[1] for e in batch]
             try:
                 try:

@@ -495,13 +495,37 @@ def test_second_lane_serves_when_lane0_is_stuck():
     t0 = time.monotonic()
     first = mb.submit("stuck", 0)
     time.sleep(0.05)
-    if not mb._lane0_busy:                       # lane 1 happened to take the stuck job: nothing to show on this run
-        gate.set(); first.result(5); mb.close(); return
+    assert mb._lane0_busy                        # an idle lane 0 always takes the head
     futs = [mb.submit("a", i) for i in range(6)]  # more than lane_max_waiting: lane 1 defers at first ...
     assert [f.result(5) for f in futs] == list(range(6))            # ... and serves once lane 0 has been away > lane0_stall_s
     assert all(lane == 1 for lane, key, n, t in served if key == "a") and time.monotonic() - t0 < 3.0
     gate.set()
     assert first.result(5) == 0
+    mb.close()
+
+
+def test_lone_caller_stays_on_lane0():
+    """One caller at a time never reaches the other lanes (each would allocate its own workspace, buffers and graphs on first
+    use): lane k > 0 only serves while lane 0 is inside a pass.  Two concurrent callers do use both."""
+    import threading, time
+    from sdlcm_amd.backends.batching import MicroBatcher
+    served = []
+
+    def run(key, items, lane):
+        time.sleep(0.02)
+        served.append(lane)
+        return list(items)
+
+    mb = MicroBatcher(run, max_batch=8, lanes=2)
+    for i in range(25):
+        assert mb.submit("k", i).result(5) == i
+    assert set(served) == {0}
+    served.clear()
+    out = []
+    ts = [threading.Thread(target=lambda j=j: out.extend(mb.submit("k", 100 * j + i).result(5) for i in range(10))) for j in range(2)]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    assert sorted(out) == sorted(100 * j + i for j in range(2) for i in range(10))
+    assert set(served) == {0, 1}
     mb.close()
 
 
