@@ -1037,6 +1037,7 @@ def test_segmented_accumulation_is_bit_identical_to_split(kind, B, H, W, Cin, Co
 
 
 @pytest.mark.parametrize("B,heads,Sq,Sk,d,causal", [(1, 8, 4096, 4096, 40, False), (2, 8, 1024, 1024, 80, False), (1, 8, 3185, 3185, 40, False),
+                                                  (1, 20, 1024, 1024, 64, False), (1, 8, 1000, 1000, 80, False),
                                                   (1, 8, 256, 77, 160, False), (2, 12, 77, 77, 64, True)])
 def test_attention_workgroup_shape_is_bit_neutral(B, heads, Sq, Sk, d, causal):
     """Workgroup shapes of one attention kernel (register-staged kernel: 64 / 128 query rows; streaming kernel of the long
