@@ -176,7 +176,8 @@ int lcm_set_conv_impl(int impl);
 /* ---- 3x3 convolution from the fp32 NCHW latent (UNet conv_in; VAE post_quant_conv+decoder.conv_in) ----
  * in: fp32 [B,4,H,W]; optional pre-transform z = pre_w(4x4 fp32, row=out) * (in * in_scale) + pre_b
  * (AutoencoderKL: latents / scaling_factor -> post_quant_conv, backends/rknnlcm.py:614).
- * W: fp16 [Cout][9][4]; out: fp16 [B,H,W,Cout].  Cout % 8 == 0.
+ * W: fp16 [Cout][9][4]; out: fp16 [B,H,W,Cout].  Cout % 16 == 0.  The fp32 input enters the MFMA as fp16 hi + fp16 lo parts
+ * (two K slots per value against the same weight): input precision ~22 bits, fp32 accumulation.
  */
 int lcm_conv3x3_c4_f32in(const void* in, const void* pre_w, const void* pre_b, float in_scale,
                          const void* W, const void* bias, void* out, int B, int H, int Wd, int Cout, void* stream);
@@ -250,9 +251,16 @@ int lcm_transpose_f16(const void* in, int ldi, void* out, int ldo, int R, int C,
  */
 int lcm_linear_smallm_f16(const void* x, int ldx, const void* W, const void* bias, const void* res, int ldr,
                           void* out, int ldo, int M, int N, int K, int silu_in, int silu_out, void* stream);
+/* The same with any M and with x / res given for fewer rows than M: row m reads x[m % x_rows] and res[m % res_rows]
+ * (the time-embedding MLP of all sampler steps in one launch per layer: rows step-major (step, image), the guidance embedding
+ * and SDXL's added embedding given once per image).  A row's result does not depend on M. */
+int lcm_linear_rows_f16(const void* x, int ldx, int x_rows, const void* W, const void* bias, const void* res, int ldr,
+                        int res_rows, void* out, int ldo, int M, int N, int K, int silu_in, int silu_out, void* stream);
 
 /* ---- Timesteps(flip_sin_to_cos=True, freq_shift=0): out fp16 [B][dim] = [cos | sin](t * f) ---- */
 int lcm_timestep_embedding(float t, void* out, int B, int dim, void* stream);
+/* nsteps <= 64 timesteps (host array) at once: out fp16 [nsteps][B][dim] */
+int lcm_timestep_embedding_steps(const float* t_host, int nsteps, void* out, int B, int dim, void* stream);
 
 /* ---- LCMScheduler.step (backends/rknnlcm.py:596-599), epsilon prediction, fp32 state ----
  * eps: fp32 NHWC [B,h,w,4] (conv_out); eps_uncond != NULL applies classifier-free guidance first.

@@ -5,70 +5,99 @@
 #include "common.h"
 
 // ---------------------------------------------------------------------------------------------
-// conv3x3 from fp32 NCHW latents (Cin = 4) -> fp16 pixel-major [B,H,W,Cout].
-// One thread = one pixel x 8 output channels; the 36 (transformed) inputs of the pixel are gathered once
-// per thread, weights [Cout][36] live in LDS.
+// conv3x3 from fp32 NCHW latents (Cin = 4) -> fp16 pixel-major [B,H,W,Cout], on the matrix pipe.
+// K = 9 taps x 4 channels = 36.  The fp32 input (after in_scale and the optional 4x4 pre-transform) is split into
+// hi = fp16(x) and lo = fp16(x - hi): K slots 0..35 carry hi, 36..71 lo against the SAME weights, 72..95 zeros -- three
+// v_mfma_f32_16x16x32_f16 per 16 pixels x 16 channels with the input kept to ~22 bits (fp16 x fp16 products are exact in the
+// fp32 accumulator), i.e. the accuracy of the fp32 multiply-add form this replaces (which spent ~700 VALU instructions per
+// pixel and 8 channels: 74 us for the batch-8 UNet conv_in against ~8 us of output writes).
+// A = weights (rows = output channels) from LDS, B = the pixel's 96 slots built in registers; D: lane = (pixel lane&15,
+// channels 4*(lane>>4)..+3) -> one 8-byte store per 16x16 tile.  A wave owns 16 consecutive pixels of the flattened
+// (b, y, x) order; workgroups walk the tiles persistently so that the weights are staged once.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void conv_c4_kernel(const float* __restrict__ in, const float* __restrict__ pre_w,
                                                       const float* __restrict__ pre_b, float in_scale,
                                                       const half_t* __restrict__ W, const half_t* __restrict__ bias,
                                                       half_t* __restrict__ out, int B, int H, int Wd, int Cout) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // weights in LDS as 16-byte chunks [k8 = 0..4][j = 0..7][g]: chunk (k8, j, g) = W[g*8 + j][8*k8 .. 8*k8+7] (zero past 36).
-    // A wave's lanes are consecutive g of one pixel, so each ds_read_b128 of a wave walks consecutive chunks: conflict-free
-    // (rows of 36 or 40 halfs per output channel put the lanes 8 rows apart -- 8- to 16-way bank conflicts).
-    half_t* ws = reinterpret_cast<half_t*>(smem);
-    const int ng = Cout >> 3;
-    for (int i = threadIdx.x; i < Cout * 10; i += 256) {    // 8-byte pieces of the [Cout][36] rows (coalesced), scattered into place
-        const int co = i / 10, q = i - co * 10;             // q = 4-element piece of the row; piece 9 is the zero pad
-        h4 v = {0, 0, 0, 0};
-        if (q < 9) v = *reinterpret_cast<const h4*>(W + co * 36 + q * 4);
-        *reinterpret_cast<h4*>(ws + (((q >> 1) * 8 + (co & 7)) * ng + (co >> 3)) * 8 + (q & 1) * 4) = v;
+    // LDS image: 16-byte chunk (sg, co) = the 8 K slots 8sg..8sg+7 of output channel co, at ((sg * Cout) + co) * 16:
+    // the 16 lanes of a fragment read consecutive chunks
+    for (int i = threadIdx.x; i < Cout * 12; i += 256) {
+        const int sg = i / Cout, co = i - sg * Cout;
+        h4 v[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int s4 = sg * 2 + h;                       // 4-slot group: part = s4 / 9 (hi, lo, zero), tap = s4 % 9
+            v[h] = (h4){0, 0, 0, 0};
+            if (s4 < 18) v[h] = *reinterpret_cast<const h4*>(W + co * 36 + (s4 % 9) * 4);
+        }
+        h8 o = {v[0][0], v[0][1], v[0][2], v[0][3], v[1][0], v[1][1], v[1][2], v[1][3]};
+        *reinterpret_cast<h8*>(smem + (sg * Cout + co) * 16) = o;
     }
     __syncthreads();
-    const long long total = (long long)B * H * Wd * ng;
-    const long long plane = (long long)H * Wd;
-    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-        const int g = (int)(idx % ng);
-        const long long pix = idx / ng;
-        const int x = (int)(pix % Wd), y = (int)((pix / Wd) % H), b = (int)(pix / plane);
-        float v[36];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = lane & 15, q = lane >> 4;
+    const int npix = B * H * Wd, ntile = (npix + 15) >> 4, plane = H * Wd;
+    float pw[16], pb[4];
+    if (pre_w) {
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int iy = y + tap / 3 - 1, ix = x + tap % 3 - 1;
-            float z[4] = {0.f, 0.f, 0.f, 0.f};
-            if (iy >= 0 && iy < H && ix >= 0 && ix < Wd) {
-                float r[4];
+        for (int i = 0; i < 16; ++i) pw[i] = pre_w[i];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) r[c] = in[((long long)(b * 4 + c) * H + iy) * Wd + ix] * in_scale;
-                if (pre_w) {
+        for (int i = 0; i < 4; ++i) pb[i] = pre_b[i];
+    }
+    for (int t = blockIdx.x * 4 + wave; t < ntile; t += gridDim.x * 4) {
+        const int pix = t * 16 + n;
+        const bool live = pix < npix;
+        const int b = pix / plane, rem = pix - b * plane;
+        const int y = rem / Wd, x = rem - y * Wd;
+        h8 xf[3];
 #pragma unroll
-                    for (int o = 0; o < 4; ++o)
-                        z[o] = pre_b[o] + pre_w[o * 4] * r[0] + pre_w[o * 4 + 1] * r[1] + pre_w[o * 4 + 2] * r[2] +
-                               pre_w[o * 4 + 3] * r[3];
-                } else {
+        for (int s = 0; s < 3; ++s) {
+            half_t e[8];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) z[c] = r[c];
+            for (int h = 0; h < 2; ++h) {
+                const int s4 = 8 * s + 2 * q + h;
+                const int part = s4 >= 18 ? 2 : (s4 >= 9 ? 1 : 0), tap = s4 - 9 * (s4 >= 18 ? 2 : (s4 >= 9 ? 1 : 0));
+                const int iy = y + tap / 3 - 1, ix = x + tap % 3 - 1;
+                float z[4] = {0.f, 0.f, 0.f, 0.f};
+                if (live && part < 2 && iy >= 0 && iy < H && ix >= 0 && ix < Wd) {
+                    float r[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) r[c] = in[((b * 4 + c) * H + iy) * Wd + ix] * in_scale;
+                    if (pre_w) {
+#pragma unroll
+                        for (int o = 0; o < 4; ++o)
+                            z[o] = pb[o] + pw[o * 4] * r[0] + pw[o * 4 + 1] * r[1] + pw[o * 4 + 2] * r[2] + pw[o * 4 + 3] * r[3];
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) z[c] = r[c];
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const half_t hi = (half_t)z[c];
+                    e[h * 4 + c] = part == 0 ? hi : (half_t)(z[c] - (float)hi);
                 }
             }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) v[tap * 4 + c] = z[c];
+            xf[s] = (h8){e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7]};
         }
-        h8 o;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int co = g * 8 + j;
-            float acc = bias ? (float)bias[co] : 0.f;
-#pragma unroll
-            for (int k8 = 0; k8 < 5; ++k8) {                // five 16-byte LDS reads per output channel (were 36 two-byte ones)
-                const h8 w8 = *reinterpret_cast<const h8*>(ws + ((k8 * 8 + j) * ng + g) * 8);
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    if (k8 * 8 + k < 36) acc += v[k8 * 8 + k] * (float)w8[k];
+        half_t* orow = out + (long long)pix * Cout + 4 * q;
+        for (int ct = 0; ct < Cout; ct += 16) {
+            f4 acc = {0.f, 0.f, 0.f, 0.f};
+            if (bias) {
+                const h4 b4 = *reinterpret_cast<const h4*>(bias + ct + 4 * q);
+                acc = (f4){(float)b4[0], (float)b4[1], (float)b4[2], (float)b4[3]};
             }
-            o[j] = (half_t)acc;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const h8 wf = *reinterpret_cast<const h8*>(smem + (((s * 4 + q) * Cout) + ct + n) * 16);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf[s], acc, 0, 0, 0);
+            }
+            if (live) {
+                const h4 o = {(half_t)acc[0], (half_t)acc[1], (half_t)acc[2], (half_t)acc[3]};
+                *reinterpret_cast<h4*>(orow + ct) = o;
+            }
         }
-        *reinterpret_cast<h8*>(out + pix * Cout + g * 8) = o;
     }
 }
 
@@ -76,12 +105,19 @@ extern "C" int lcm_conv3x3_c4_f32in(const void* in, const void* pre_w, const voi
                                     const void* W, const void* bias, void* out, int B, int H, int Wd, int Cout,
                                     void* stream) {
     LCM_REQUIRE(in && W && out, "conv_c4: null pointer");
-    LCM_REQUIRE(B > 0 && H > 0 && Wd > 0 && Cout % 8 == 0 && Cout * 80 <= 64 * 1024, "conv_c4: bad shape (Cout %d)", Cout);
+    LCM_REQUIRE(B > 0 && H > 0 && Wd > 0 && Cout % 16 == 0 && Cout * 192 <= 160 * 1024, "conv_c4: bad shape (Cout %d)", Cout);
+    LCM_REQUIRE((long long)B * 4 * H * Wd < (1ll << 31), "conv_c4: input too large");
     LCM_REQUIRE((pre_w == nullptr) == (pre_b == nullptr), "conv_c4: pre_w/pre_b must come together");
-    const long long total = (long long)B * H * Wd * (Cout / 8);
-    // at most ~4 workgroups per CU: the weight staging of a workgroup is amortised over several pixels per thread
-    const int grid = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
-    hipLaunchKernelGGL(conv_c4_kernel, dim3(grid), dim3(256), Cout * 40 * 2, (hipStream_t)stream, (const float*)in,
+    const int smem = Cout * 192;
+    static int attr_set = 0;
+    if (smem > attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_c4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = 160 * 1024;
+    }
+    const long long ntile = ((long long)B * H * Wd + 15) / 16;
+    // persistent: the weights are staged once per workgroup; at most two workgroups per CU
+    const int grid = (int)((ntile + 3) / 4 < 512 ? (ntile + 3) / 4 : 512);
+    hipLaunchKernelGGL(conv_c4_kernel, dim3(grid), dim3(256), smem, (hipStream_t)stream, (const float*)in,
                        (const float*)pre_w, (const float*)pre_b, in_scale, (const half_t*)W, (const half_t*)bias,
                        (half_t*)out, B, H, Wd, Cout);
     LCM_CHECK_LAUNCH("conv_c4");
@@ -258,77 +294,97 @@ extern "C" int lcm_conv3x3_smalln(const void* in, const void* W, const void* bia
 }
 
 // ---------------------------------------------------------------------------------------------
-// small-M linear: one wave per output feature n, lanes stride K in 16-byte chunks.
+// small-M linear: one wave per output feature n, lanes stride K in 16-byte chunks; rows in blocks of 16 (the weight row is
+// re-read from L1 per block).  Row m reads x[m % x_rows] and res[m % res_rows]: the time-embedding MLP of ALL sampler steps
+// runs as one launch per layer (rows = step-major (step, image)) with the per-request inputs (guidance embedding, SDXL
+// added embedding) given once.  A row's fp32 summation order does not depend on M.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void linear_smallm_kernel(const half_t* __restrict__ x, int ldx,
+__global__ __launch_bounds__(256) void linear_smallm_kernel(const half_t* __restrict__ x, int ldx, int x_rows,
                                                             const half_t* __restrict__ W, const half_t* __restrict__ bias,
-                                                            const half_t* __restrict__ res, int ldr,
+                                                            const half_t* __restrict__ res, int ldr, int res_rows,
                                                             half_t* __restrict__ out, int ldo, int M, int N, int K,
                                                             int silu_in, int silu_out) {
     const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= N) return;
-    float acc[16];
-#pragma unroll
-    for (int m = 0; m < 16; ++m) acc[m] = 0.f;
     const half_t* wr = W + (long long)n * K;
-    for (int k = lane * 8; k < K; k += 512) {
-        h8 w = *reinterpret_cast<const h8*>(wr + k);
+    for (int m0 = 0; m0 < M; m0 += 16) {
+        float acc[16];
+#pragma unroll
+        for (int m = 0; m < 16; ++m) acc[m] = 0.f;
+        for (int k = lane * 8; k < K; k += 512) {
+            h8 w = *reinterpret_cast<const h8*>(wr + k);
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                if (m0 + m < M) {
+                    h8 xv = *reinterpret_cast<const h8*>(x + (long long)((m0 + m) % x_rows) * ldx + k);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        float f = (float)xv[j];
+                        if (silu_in) f = silu_f(f);
+                        acc[m] += f * (float)w[j];
+                    }
+                }
+            }
+        }
 #pragma unroll
         for (int m = 0; m < 16; ++m) {
-            if (m < M) {
-                h8 xv = *reinterpret_cast<const h8*>(x + (long long)m * ldx + k);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    float f = (float)xv[j];
-                    if (silu_in) f = silu_f(f);
-                    acc[m] += f * (float)w[j];
+            if (m0 + m < M) {
+                float v = wave_sum(acc[m]);
+                if (lane == 0) {
+                    if (bias) v += (float)bias[n];
+                    if (res) v += (float)res[(long long)((m0 + m) % res_rows) * ldr + n];
+                    if (silu_out) v = silu_f(v);
+                    out[(long long)(m0 + m) * ldo + n] = (half_t)v;
                 }
             }
         }
     }
-#pragma unroll
-    for (int m = 0; m < 16; ++m) {
-        if (m < M) {
-            float v = wave_sum(acc[m]);
-            if (lane == 0) {
-                if (bias) v += (float)bias[n];
-                if (res) v += (float)res[(long long)m * ldr + n];
-                if (silu_out) v = silu_f(v);
-                out[(long long)m * ldo + n] = (half_t)v;
-            }
-        }
-    }
+}
+
+extern "C" int lcm_linear_rows_f16(const void* x, int ldx, int x_rows, const void* W, const void* bias, const void* res, int ldr,
+                                   int res_rows, void* out, int ldo, int M, int N, int K, int silu_in, int silu_out, void* stream) {
+    LCM_REQUIRE(x && W && out, "linear_rows: null pointer");
+    LCM_REQUIRE(M >= 1 && M <= 4096 && N > 0 && K > 0 && K % 8 == 0 && ldx % 8 == 0 && x_rows >= 1 && (!res || res_rows >= 1),
+                "linear_rows: bad shape M=%d N=%d K=%d x_rows=%d res_rows=%d", M, N, K, x_rows, res_rows);
+    hipLaunchKernelGGL(linear_smallm_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const half_t*)x, ldx, x_rows,
+                       (const half_t*)W, (const half_t*)bias, (const half_t*)res, ldr, res ? res_rows : 1, (half_t*)out, ldo, M, N, K,
+                       silu_in, silu_out);
+    LCM_CHECK_LAUNCH("linear_rows");
+    return LCM_OK;
 }
 
 extern "C" int lcm_linear_smallm_f16(const void* x, int ldx, const void* W, const void* bias, const void* res, int ldr,
                                      void* out, int ldo, int M, int N, int K, int silu_in, int silu_out, void* stream) {
-    LCM_REQUIRE(x && W && out, "linear_smallm: null pointer");
-    LCM_REQUIRE(M >= 1 && M <= 16 && N > 0 && K > 0 && K % 8 == 0 && ldx % 8 == 0, "linear_smallm: bad shape M=%d N=%d K=%d", M, N, K);
-    hipLaunchKernelGGL(linear_smallm_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const half_t*)x, ldx,
-                       (const half_t*)W, (const half_t*)bias, (const half_t*)res, ldr, (half_t*)out, ldo, M, N, K,
-                       silu_in, silu_out);
-    LCM_CHECK_LAUNCH("linear_smallm");
-    return LCM_OK;
+    LCM_REQUIRE(M >= 1 && M <= 16, "linear_smallm: bad shape M=%d N=%d K=%d", M, N, K);
+    return lcm_linear_rows_f16(x, ldx, M, W, bias, res, ldr, M, out, ldo, M, N, K, silu_in, silu_out, stream);
 }
 
 // ---------------------------------------------------------------------------------------------
-__global__ void timestep_embedding_kernel(float t, half_t* __restrict__ out, int B, int dim) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+struct StepTimes { float t[64]; };
+__global__ void timestep_embedding_kernel(StepTimes ts, half_t* __restrict__ out, int nsteps, int B, int dim) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // rows step-major: (step, image)
     const int half = dim >> 1;
-    if (i >= B * dim) return;
+    if (i >= nsteps * B * dim) return;
     const int j = i % dim;
+    const float t = ts.t[i / (B * dim)];
     const int k = j < half ? j : j - half;
     const float f = expf(-9.210340371976184f * (float)k / (float)half);   // ln(10000)
     const float a = t * f;
     out[i] = (half_t)(j < half ? cosf(a) : sinf(a));
 }
 
-extern "C" int lcm_timestep_embedding(float t, void* out, int B, int dim, void* stream) {
-    LCM_REQUIRE(out && B > 0 && dim > 0 && dim % 2 == 0, "timestep_embedding: bad shape");
-    hipLaunchKernelGGL(timestep_embedding_kernel, dim3((B * dim + 255) / 256), dim3(256), 0, (hipStream_t)stream, t,
-                       (half_t*)out, B, dim);
+extern "C" int lcm_timestep_embedding_steps(const float* t_host, int nsteps, void* out, int B, int dim, void* stream) {
+    LCM_REQUIRE(t_host && out && B > 0 && dim > 0 && dim % 2 == 0 && nsteps >= 1 && nsteps <= 64, "timestep_embedding: bad shape (steps %d)", nsteps);
+    StepTimes ts;
+    for (int i = 0; i < 64; ++i) ts.t[i] = i < nsteps ? t_host[i] : 0.f;
+    hipLaunchKernelGGL(timestep_embedding_kernel, dim3((nsteps * B * dim + 255) / 256), dim3(256), 0, (hipStream_t)stream, ts,
+                       (half_t*)out, nsteps, B, dim);
     LCM_CHECK_LAUNCH("timestep_embedding");
     return LCM_OK;
+}
+
+extern "C" int lcm_timestep_embedding(float t, void* out, int B, int dim, void* stream) {
+    return lcm_timestep_embedding_steps(&t, 1, out, B, dim, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -47,6 +47,8 @@ _SIGS = {
     "lcm_transpose_f16": [_vp, _i, _vp, _i, _i, _i, _i, _i64, _i64, _vp],
     "lcm_linear_smallm_f16": [_vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "lcm_timestep_embedding": [_f, _vp, _i, _i, _vp],
+    "lcm_linear_rows_f16": [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "lcm_timestep_embedding_steps": [_vp, _i, _vp, _i, _i, _vp],
     "lcm_scheduler_step": [_vp, _vp, _f, _vp, _vp, C.POINTER(C.c_float), _i, _i, _i, _i, _vp],
     "lcm_latents_pool8": [_vp, _vp, _i, _i, _i, _vp],
     "lcm_graph_begin": [_vp],

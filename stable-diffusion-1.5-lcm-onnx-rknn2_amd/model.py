@@ -354,8 +354,40 @@ class UNetHip(_Net):
         temb = self.buf.get("temb", B, self.temb_dim)
         ops.linear_smallm(h, w["te.linear_2.w"], temb, B, self.temb_dim, self.temb_dim, bias=w["te.linear_2.b"], res=aug, silu_out=True)
         ta = self.buf.get("temb_all", B, self.temb_total)
-        ops.linear_smallm(temb, w["temb_all.w"], ta, B, self.temb_total, self.temb_dim, bias=w["temb_all.b"])
+        self._temb_proj(temb, ta)
         return ta
+
+    MAX_HOISTED_STEPS = 64
+
+    def time_embed_all(self, ts, wemb, B, aug=None):
+        """time_embed of every sampler step in one launch per layer: -> [len(ts) * B, temb_total], rows step-major (the rows of
+        step i are [i*B, (i+1)*B)).  Bit-identical to time_embed per step (a row's summation order does not depend on M); the
+        stacked 20160 x 1280 projection is streamed once per pass instead of once per step."""
+        w = self.w
+        S, ch0 = len(ts), self.cfg["block_out_channels"][0]
+        M = S * B
+        e0 = self.buf.get("te0_all", M, ch0)
+        ops.timestep_embedding_steps([float(t) for t in ts], e0, B, ch0)
+        if self.has_cond and wemb is not None:
+            e1 = self.buf.get("te1_all", M, ch0)
+            ops.linear_rows(wemb, w["te.cond.w"], e1, M, ch0, wemb.shape[1], x_rows=B, res=e0)
+        else:
+            e1 = e0
+        h = self.buf.get("te_h_all", M, self.temb_dim)
+        ops.linear_rows(e1, w["te.linear_1.w"], h, M, self.temb_dim, ch0, bias=w["te.linear_1.b"], silu_out=True)
+        temb = self.buf.get("temb_rows", M, self.temb_dim)
+        ops.linear_rows(h, w["te.linear_2.w"], temb, M, self.temb_dim, self.temb_dim, bias=w["te.linear_2.b"], res=aug, res_rows=B,
+                        silu_out=True)
+        ta = self.buf.get("temb_all_rows", M, self.temb_total)
+        self._temb_proj(temb, ta)
+        return ta
+
+    def _temb_proj(self, temb, ta):
+        """All time_emb_proj layers as ONE MFMA GEMM (N = 20160 for SD1.5), every row its own "image" (img_rows = 1: the K
+        partition is that of a single row, whatever the number of steps and requests stacked here) -- the one-wave-per-feature
+        kernel is VALU-bound from ~16 rows on (330 us for the 32 rows of a batch-8 4-step pass, against ~15 us)."""
+        w = self.w
+        ops.gemm(temb, w["temb_all.w"], ta, bias=w["temb_all.b"], img_rows=1)
 
     def _res(self, p, x, C1, Cout, B, H, W, ta, x2=None, C2=0, out_role="res_out", x_st=None, x2_st=None):
         off, n = self.temb_off[p]
@@ -404,12 +436,14 @@ class UNetHip(_Net):
         ops.gemm(h, w[p + ".proj_out.w"], out, bias=w[p + ".proj_out.b"], res=x, stats=out_st, img_rows=HW)
         return out, out_st
 
-    def forward(self, lat, t, kv_all, wemb, B, h, w_, eps_out, taps=None, aug=None):
-        """lat fp32 [B,4,h,w] -> eps_out fp32 [B,h,w,4] (pixel-major).  aug: SDXL additional embedding (encode_added)."""
+    def forward(self, lat, t, kv_all, wemb, B, h, w_, eps_out, taps=None, aug=None, ta=None):
+        """lat fp32 [B,4,h,w] -> eps_out fp32 [B,h,w,4] (pixel-major).  aug: SDXL additional embedding (encode_added).
+        ta: this step's rows of time_embed_all (the sampler computes all steps ahead of the loop); None: computed here."""
         cfg, wt = self.cfg, self.w
         boc = cfg["block_out_channels"]
         nb = len(boc)
-        ta = self.time_embed(t, wemb, B, aug)
+        if ta is None:
+            ta = self.time_embed(t, wemb, B, aug)
         H, W = h, w_
         x = self.buf.get("skip0", B * H * W, boc[0])
         ops.conv3x3_c4(lat, wt["conv_in.w"], x, B, H, W, boc[0], bias=wt["conv_in.b"])

@@ -367,6 +367,24 @@ def linear_smallm(x, w, out, M, N, K, *, bias=None, res=None, silu_in=False, sil
     return out
 
 
+def linear_rows(x, w, out, M, N, K, *, x_rows=None, bias=None, res=None, res_rows=None, silu_in=False, silu_out=False):
+    """linear_smallm for any M; row m reads x[m % x_rows] and res[m % res_rows] (lcm_linear_rows_f16)."""
+    L = _lib.load()
+    rc = L.lcm_linear_rows_f16(_p(x), x.stride(0), M if x_rows is None else x_rows, _p(w), _p(bias), _p(res),
+                               res.stride(0) if res is not None else 0, M if res_rows is None else res_rows, _p(out), out.stride(0),
+                               M, N, K, int(silu_in), int(silu_out), _stream())
+    _lib.check(rc, "lcm_linear_rows_f16")
+    return out
+
+
+def timestep_embedding_steps(ts, out, B, dim):
+    """out [len(ts) * B, dim], rows step-major."""
+    L = _lib.load()
+    arr = (C.c_float * len(ts))(*[float(t) for t in ts])
+    _lib.check(L.lcm_timestep_embedding_steps(arr, len(ts), _p(out), B, dim, _stream()), "lcm_timestep_embedding_steps")
+    return out
+
+
 def timestep_embedding(t, out, B, dim):
     L = _lib.load()
     _lib.check(L.lcm_timestep_embedding(float(t), _p(out), B, dim, _stream()), "lcm_timestep_embedding")

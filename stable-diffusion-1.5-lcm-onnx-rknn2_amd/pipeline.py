@@ -193,8 +193,12 @@ class LcmHipPipeline:
         kv = unet.encode_context(P.ehs, UB)
         aug = unet.encode_added(P.add_in, UB) if unet.has_added else None
         wemb = P.wemb if unet.has_cond else None
+        # the time-embedding MLP + all time_emb_proj of EVERY step ahead of the loop (they depend on the schedule and the
+        # request's guidance only): 5 launches per pass instead of 4 per step
+        ta_all = unet.time_embed_all([int(t) for t in ts], wemb, UB, aug) if len(ts) <= unet.MAX_HOISTED_STEPS else None
         for i, t in enumerate(ts):
-            unet.forward(P.lat, int(t), kv, wemb, UB, h, w, P.eps, taps=taps if i == 0 else None, aug=aug)
+            unet.forward(P.lat, int(t), kv, wemb, UB, h, w, P.eps, taps=taps if i == 0 else None, aug=aug,
+                         ta=ta_all[i * UB:(i + 1) * UB] if ta_all is not None else None)
             coef, last = self.sched.step_coefficients(ts, i)
             noise = P.noise[min(i, P.noise.shape[0] - 1)]
             if P.do_cfg:   # rows [0,B) = negative prompt, [B,2B) = prompt

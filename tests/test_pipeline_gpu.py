@@ -63,6 +63,26 @@ def test_unet_forward_parity(state):
     assert e.max() < 2e-2
 
 
+def test_time_embedding_of_all_steps_equals_per_step(state):
+    """UNetHip.time_embed_all (the sampler's form: every step's TimestepEmbedding + guidance embedding + all time_emb_proj in
+    one launch per layer, rows step-major) is bit-identical to time_embed called per step, for batch sizes on both sides of
+    the kernel's 16-row block."""
+    from sdlcm_amd.pipeline import guidance_scale_embedding
+    hip = state["hip"]
+    u = hip.unet
+    ts = [999, 759, 499, 259, 19]
+    for B in (1, 3, 8):
+        wemb = torch.from_numpy(guidance_scale_embedding(np.linspace(0.0, 7.0, B).astype(np.float32), 256)).to(hip.device, torch.float16)
+        with torch.cuda.stream(hip.stream):
+            all_rows = u.time_embed_all(ts, wemb, B).clone()
+            per_step = [u.time_embed(t, wemb, B).clone() for t in ts]
+            hip.stream.synchronize()
+        assert all_rows.shape == (len(ts) * B, u.temb_total)
+        for i in range(len(ts)):
+            assert torch.equal(all_rows[i * B:(i + 1) * B], per_step[i]), (B, i)
+        assert not torch.equal(per_step[0], per_step[1])
+
+
 def test_vae_decode_parity(state):
     hip, ora = state["hip"], state["ora"]
     B, h, w = 2, 16, 16
