@@ -189,6 +189,13 @@ int lcm_conv3x3_c4_f32in(const void* in, const void* pre_w, const void* pre_b, f
  */
 int lcm_conv3x3_smalln(const void* in, const void* W, const void* bias, void* out, void* out_f32,
                        int B, int H, int Wd, int Cin, int Cout, int mode, void* stream);
+/* The same behind a fused GroupNorm-apply (+SiLU when silu != 0): in is the RAW tensor, gn_scale / gn_shift fp32 [B][Cin] the
+ * tables of lcm_groupnorm_from_stats_f16 (out == NULL form) -- conv_norm_out -> SiLU -> conv_out of the UNet and of the
+ * AutoencoderKL decoder without the normalised tensor in memory.  Cin % 64 == 0 (MFMA kernel; the choice of kernel depends on
+ * Cin only).  gn_scale == NULL: identical to lcm_conv3x3_smalln. */
+int lcm_conv3x3_smalln_gn(const void* in, const void* gn_scale, const void* gn_shift, int silu, const void* W,
+                          const void* bias, void* out, void* out_f32, int B, int H, int Wd, int Cin, int Cout,
+                          int mode, void* stream);
 
 /* ---- GroupNorm (+SiLU) over [B,HW,C1(+C2)] (ResnetBlock2D.norm1/2, Transformer2DModel.norm, conv_norm_out) ----
  * x2 != NULL normalises the channel concatenation [x | x2] (fused torch.cat of the skip) and writes the

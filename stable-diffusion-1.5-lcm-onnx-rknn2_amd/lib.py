@@ -39,6 +39,7 @@ _SIGS = {
     "lcm_groupnorm_from_stats_f16": [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp],
     "lcm_conv3x3_c4_f32in": [_vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "lcm_conv3x3_smalln": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "lcm_conv3x3_smalln_gn": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "lcm_groupnorm_f16": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp],
     "lcm_layernorm_f16": [_vp, _vp, _vp, _vp, _i, _i, _f, _vp],
     "lcm_attention_f16": [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp],

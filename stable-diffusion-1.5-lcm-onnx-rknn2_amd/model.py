@@ -113,6 +113,19 @@ class _Net:
             ops.groupnorm(x, gamma, beta, out, B, HW, C1, ws, x2=x2, C2=C2, eps=eps, silu=silu)
         return out
 
+    def _norm_conv_out(self, x, norm, st, hn, out, B, H, W, ch, cout, eps, *, mode, out_f32=None):
+        """conv_norm_out -> SiLU -> conv_out.  With the producer's fused statistics and 64-aligned channels the GroupNorm is
+        applied inside the conv's staging pass (the normalised tensor never exists in memory); the choice depends on the layer's
+        shape only, and both forms feed the conv the same fp16 values."""
+        wt = self.w
+        if FUSED_GN_STATS and st is not None and st.P > 0 and ch % 64 == 0:
+            sc_t, sh_t = ops.groupnorm_tables_from_stats(wt[norm + ".g"], wt[norm + ".b"], B, H * W, ch, st, self.gn_ws(B, H * W, ch), eps=eps)
+            ops.conv3x3_smalln(x, wt["conv_out.w"], out, B, H, W, ch, cout, bias=wt["conv_out.b"], mode=mode, out_f32=out_f32,
+                               gn_scale=sc_t, gn_shift=sh_t, silu=True)
+        else:
+            self.norm(x, wt[norm + ".g"], wt[norm + ".b"], hn, B, H * W, ch, x_st=st, eps=eps)
+            ops.conv3x3_smalln(hn, wt["conv_out.w"], out, B, H, W, ch, cout, bias=wt["conv_out.b"], mode=mode, out_f32=out_f32)
+
     def gn_ws(self, B, HW, C):
         """fp32 scratch of the GroupNorm kernels (chunk partials + [B][C] scale / shift tables).  One tensor per
         (B, HW, C), allocated once and never replaced: captured hipGraphs bake the raw pointer in, so growing a shared
@@ -515,8 +528,7 @@ class UNetHip(_Net):
                 H, W, x = Ho, Wo, y
                 tap(f"up_blocks.{i}.upsamplers.0", x, ch, H, W)
         hn = self.buf.get("gn", B * H * W, ch)
-        self.norm(x, wt["conv_norm_out.g"], wt["conv_norm_out.b"], hn, B, H * W, ch, x_st=st, eps=cfg["norm_eps"])
-        ops.conv3x3_smalln(hn, wt["conv_out.w"], eps_out, B, H, W, ch, cfg["out_channels"], bias=wt["conv_out.b"], mode=0)
+        self._norm_conv_out(x, "conv_norm_out", st, hn, eps_out, B, H, W, ch, cfg["out_channels"], cfg["norm_eps"], mode=0)
         return eps_out
 
 
@@ -711,7 +723,5 @@ class VAEDecoderHip(_Net):
                 H, W, x = 2 * H, 2 * W, y
                 tap(f"decoder.up_blocks.{i}.upsamplers.0", x, ch, H, W)
         hn = self.buf.get("gn", B * H * W, ch)
-        self.norm(x, wt["norm_out.g"], wt["norm_out.b"], hn, B, H * W, ch, x_st=st, eps=1e-6)
-        ops.conv3x3_smalln(hn, wt["conv_out.w"], rgb_out, B, H, W, ch, cfg["out_channels"], bias=wt["conv_out.b"], mode=1,
-                           out_f32=img_f32)
+        self._norm_conv_out(x, "norm_out", st, hn, rgb_out, B, H, W, ch, cfg["out_channels"], 1e-6, mode=1, out_f32=img_f32)
         return rgb_out

@@ -278,9 +278,14 @@ def conv3x3_c4(lat_f32, w, out, B, H, W, Cout, *, bias=None, pre_w=None, pre_b=N
     return out
 
 
-def conv3x3_smalln(x, w, out, B, H, W, Cin, Cout, *, bias=None, mode=0, out_f32=None):
+def conv3x3_smalln(x, w, out, B, H, W, Cin, Cout, *, bias=None, mode=0, out_f32=None, gn_scale=None, gn_shift=None, silu=True):
+    """gn_scale / gn_shift (groupnorm_tables_from_stats): x is the raw tensor, GroupNorm-apply (+SiLU) fused into the staging."""
     L = _lib.load()
-    rc = L.lcm_conv3x3_smalln(_p(x), _p(w), _p(bias), _p(out), _p(out_f32), B, H, W, Cin, Cout, mode, _stream())
+    if gn_scale is not None:
+        rc = L.lcm_conv3x3_smalln_gn(_p(x), _p(gn_scale), _p(gn_shift), 1 if silu else 0, _p(w), _p(bias), _p(out), _p(out_f32),
+                                     B, H, W, Cin, Cout, mode, _stream())
+    else:
+        rc = L.lcm_conv3x3_smalln(_p(x), _p(w), _p(bias), _p(out), _p(out_f32), B, H, W, Cin, Cout, mode, _stream())
     _lib.check(rc, "lcm_conv3x3_smalln")
     return out
 

@@ -534,8 +534,8 @@ def test_conv_c4(pre, B, H, W, Cout):
 @pytest.mark.parametrize("Cin,Cout,mode,shape", [(320, 4, 0, (2, 20, 12)), (128, 3, 1, (2, 20, 12)), (256, 3, 1, (2, 20, 12)),
                                                  (128, 3, 1, (1, 9, 72)), (128, 4, 0, (3, 5, 33)), (64, 3, 1, (1, 8, 40))])
 def test_conv_smalln(Cin, Cout, mode, shape):
-    """conv_out (<= 4 output channels).  Cin 128 / 256 take the row-walking kernel (sliding 3x3 window along runs of 32 pixels:
-    widths 12, 33, 72 give a short run, a 1-pixel tail and a ragged third run), the others the per-pixel kernel."""
+    """conv_out (<= 4 output channels).  Cin % 64 == 0 takes the MFMA kernel (8 x 16 pixel patches: the sizes give ragged
+    patches in both directions), other Cin the VALU kernels."""
     B, H, W = shape
     x = rnd(B, Cin, H, W, seed=1)
     w = rnd(Cout, Cin, 3, 3, seed=2, scale=(9 * Cin) ** -0.5)
@@ -555,6 +555,39 @@ def test_conv_smalln(Cin, Cout, mode, shape):
         got = o8.cpu().numpy()
         assert np.abs(got.astype(int) - exp.astype(int)).max() <= 1
         assert (got != exp).mean() < 1e-3
+
+
+@pytest.mark.parametrize("C,Cout,mode,shape", [(128, 3, 1, (2, 24, 40)), (320, 4, 0, (2, 16, 16)), (128, 3, 1, (1, 13, 21)), (64, 3, 0, (3, 8, 16)),
+                                               (128, 3, 1, (1, 20, 88)), (128, 3, 0, (2, 9, 72))])
+def test_conv_out_with_fused_groupnorm_is_bit_identical(C, Cout, mode, shape):
+    """conv_norm_out -> SiLU -> conv_out with the GroupNorm applied inside the conv's staging pass (lcm_conv3x3_smalln_gn on the
+    raw tensor + scale / shift tables) against the two-launch form (GroupNorm-apply to memory, then the conv): same statistics,
+    same fp16 rounding of the normalised value -> identical bits, RGB8 and fp32 modes."""
+    B, H, W = shape
+    M, HW, Cin0 = B * H * W, H * W, 64
+    x0 = rnd(M, Cin0, seed=1).to(DEV)
+    w0 = (rnd(C, 9 * Cin0, seed=2) * (9 * Cin0) ** -0.5).to(DEV)
+    x = torch.empty(M, C, dtype=torch.float16, device=DEV)
+    st = ops.Stats(torch.zeros(ops.stats_floats(M, C, HW), dtype=torch.float32, device=DEV))
+    ops.conv3x3(x0, w0, x, B, H, W, Cin0, C, stats=st)
+    assert st.P > 0
+    gamma, beta = (1 + 0.2 * rnd(C, seed=3)).to(DEV), (0.1 * rnd(C, seed=4)).to(DEV)
+    wo = pack3x3(rnd(Cout, C, 3, 3, seed=5, scale=(9 * C) ** -0.5)).to(DEV)
+    bo = rnd(Cout, seed=6, scale=0.1).to(DEV)
+    ws = torch.empty(max(ops.groupnorm_ws_bytes(B, HW, C) // 4, 1024), dtype=torch.float32, device=DEV)
+    hn = torch.empty(M, C, dtype=torch.float16, device=DEV)
+    ops.groupnorm_from_stats(x, gamma, beta, hn, B, HW, C, st, ws, eps=1e-6, silu=True)
+    dt = torch.uint8 if mode == 1 else torch.float32
+    a, b = torch.empty(M, Cout, dtype=dt, device=DEV), torch.full((M, Cout), 7, dtype=dt, device=DEV)
+    fa, fb = torch.empty(M, Cout, dtype=torch.float32, device=DEV), torch.full((M, Cout), 7.0, dtype=torch.float32, device=DEV)
+    ops.conv3x3_smalln(hn, wo, a, B, H, W, C, Cout, bias=bo, mode=mode, out_f32=fa)
+    sc, sh = ops.groupnorm_tables_from_stats(gamma, beta, B, HW, C, st, ws, eps=1e-6)
+    ops.conv3x3_smalln(x, wo, b, B, H, W, C, Cout, bias=bo, mode=mode, out_f32=fb, gn_scale=sc, gn_shift=sh, silu=True)
+    torch.cuda.synchronize()
+    assert torch.equal(fa, fb) and torch.equal(a, b)
+    ref = F.conv2d(from_nhwc(hn, B, H, W).float().cpu(), torch.from_numpy(np.ascontiguousarray(wo.cpu().numpy().reshape(Cout, 3, 3, C).transpose(0, 3, 1, 2))).float(),
+                   bo.float().cpu(), padding=1)
+    close(from_nhwc(fb, B, H, W), ref, rtol=1e-4, atol=1e-4, what="conv_out fused gn")
 
 
 @pytest.mark.parametrize("B,HW,C1,C2,silu,eps", [(2, 4096, 320, 0, True, 1e-5), (1, 256, 1280, 640, True, 1e-5),

@@ -3,8 +3,8 @@
 
   pass_breakdown.py <rocprof output dir> [rows]
 
-One pass = one hipGraph replay of the sampler = the kernels between two consecutive final VAE convolutions
-(conv_smalln[_row]<16>, the RGB8 epilogue).  Run it on a trace of `bench.py --no-roofline --no-extra --no-cpu-baseline`:
+One pass = one hipGraph replay of the sampler = the kernels between two consecutive latents_pool8 launches (once per
+replay, between the last scheduler step and the VAE decode: the window is a cyclic shift of one replay).  Run it on a trace of `bench.py --no-roofline --no-extra --no-cpu-baseline`:
 the roofline leg replays the dominant kernel back to back outside any pass and would otherwise land inside the window
 (round 1's breakdowns were 2x off for that kernel).  The window is taken from the timed region (the last replays) and
 is checked: every one of the last three windows must hold the same number of kernels."""
@@ -12,7 +12,7 @@ import collections, csv, glob, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 ks = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows)
-ends = [i for i, k in enumerate(ks) if "conv_smalln_" in k[2] and ("kernelILi16" in k[2] or "kernel<16>" in k[2])]
+ends = [i for i, k in enumerate(ks) if "latents_pool8" in k[2]]      # once per replay (any once-per-pass kernel delimits a window)
 assert len(ends) >= 5, "need at least 4 passes in the trace"
 wins = [(ends[-k - 1] + 1, ends[-k] + 1) for k in (1, 2, 3)]
 sizes = [b - a for a, b in wins]

@@ -12,7 +12,7 @@ ks = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"
              int(r.get("Grid_Size_X", r.get("Grid_Size", 0)) or 0) * int(r.get("Grid_Size_Y", 1) or 1) * int(r.get("Grid_Size_Z", 1) or 1),
              int(r.get("Workgroup_Size_X", r.get("Workgroup_Size", 1)) or 1) * int(r.get("Workgroup_Size_Y", 1) or 1))
             for r in rows)
-ends = [i for i, k in enumerate(ks) if "conv_smalln_" in k[2] and ("kernelILi16" in k[2] or "kernel<16>" in k[2])]
+ends = [i for i, k in enumerate(ks) if "latents_pool8" in k[2]]      # once per replay (any once-per-pass kernel delimits a window)
 assert len(ends) >= 4, "need at least 3 passes in the trace"
 a, b = ends[-3] + 1, ends[-2] + 1
 seg = ks[a:b]
