@@ -346,15 +346,25 @@ __device__ __forceinline__ h8 attn2_read_b128(int addr) {
     return *reinterpret_cast<const __attribute__((address_space(3))) h8*>((size_t)(unsigned)(addr + OFF));
 }
 
-template <int D, int WAVES>
-__global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 2 : 1) void attn2_kernel(AttnParams p, int nqb) {
+// KS = 2 (sequences of >= 1024 keys -- a property of the image, so a request computes the same bits at any batch size): the
+// keys of a query block are split over TWO groups of WAVES waves, tiles [0, ceil(n/2)) and [ceil(n/2), n); each group streams
+// its tiles through its own double buffer and keeps its own (m, l, O^T); at the end group 1 hands its state to group 0 through
+// LDS and group 0 merges (O = O1 2^(m1-m) + O2 2^(m2-m), the row sums likewise) and stores.  The dependent chain of a query
+// block -- 64 tiles at S = 4096, each a barrier, two MFMA phases and an exp2 phase that nothing overlaps at one wave per SIMD
+// (batch 1: 256 workgroups) -- halves, and every SIMD holds two waves whose MFMA and VALU phases interleave.
+template <int D, int WAVES, int KS>
+__global__ __launch_bounds__(64 * WAVES * KS, (WAVES * KS == 8) ? 2 : 1) void attn2_kernel(AttnParams p, int nqb) {      // 16 waves: one workgroup per CU, <= 128 VGPRs
     using C = Attn2Cfg<D>;
     constexpr int NP = (2 * C::NCH + WAVES - 1) / WAVES;        // DMA pieces per wave per tile
     constexpr float THR = 8.0f;                                   // deferred rescale: P <= 2^THR (fp16: no precision cost)
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(16))) char smem_all[];
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = KS == 1 ? 0 : wave_all / WAVES;               // key group
+    const int wave = KS == 1 ? wave_all : wave_all - grp * WAVES; // query sub-block (32 rows) within the workgroup
+    char* smem = smem_all + grp * C::LDS_BYTES;                   // the group's buffers and constant cells
+    const int gbase = grp * C::LDS_BYTES;
     const int l31 = lane & 31, hh = lane >> 5;
     const int v = xcd_remap_attn(blockIdx.x, gridDim.x);
     const int bh = v / nqb, qb = v - bh * nqb;
@@ -366,14 +376,15 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 2 : 1) void attn2_kernel(A
     const half_t* Vb = p.V + (long long)b * p.Sk * p.ldv + head * D;
 
     // ---- constant cells ----
+    const int gtid = wave * 64 + lane;                            // thread index within the key group
     if constexpr (C::MFOLD || C::ONES) {
-        for (int i = C::CELLS + tid * 16; i < C::LDS_BYTES; i += 64 * WAVES * 16) *reinterpret_cast<f4*>(smem + i) = (f4){0.f, 0.f, 0.f, 0.f};
+        for (int i = C::CELLS + gtid * 16; i < C::LDS_BYTES; i += 64 * WAVES * 16) *reinterpret_cast<f4*>(smem + i) = (f4){0.f, 0.f, 0.f, 0.f};
         __syncthreads();
-        if (tid < 16) {
-            char* cell = smem + C::CELLS + (tid >> 3) * C::BUFB + (tid & 7) * 8 * C::ROWB;
+        if (gtid < 16) {
+            char* cell = smem + C::CELLS + (gtid >> 3) * C::BUFB + (gtid & 7) * 8 * C::ROWB;
             if (C::ONES) *reinterpret_cast<half_t*>(cell) = (half_t)1.0f;                         // (1,0,0,0 | 0,0,0,0)
-            if (C::MFOLD && (tid & 3) == 0) { reinterpret_cast<half_t*>(cell + 16)[0] = (half_t)1.0f;   // (1,1,0,...): kb = (tid&7)>>2
-                                              reinterpret_cast<half_t*>(cell + 16)[1] = (half_t)1.0f; }
+            if (C::MFOLD && (gtid & 3) == 0) { reinterpret_cast<half_t*>(cell + 16)[0] = (half_t)1.0f;   // (1,1,0,...): kb = (gtid&7)>>2
+                                               reinterpret_cast<half_t*>(cell + 16)[1] = (half_t)1.0f; }
         }
     }
 
@@ -389,6 +400,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 2 : 1) void attn2_kernel(A
         pc_off[j] = row * (i >= C::NCH ? p.ldv : p.ldk) + C::unpos(ps, row) * 8;
     }
     const int ntiles = (p.Sk + 63) >> 6;
+    const int nhalf = KS == 1 ? ntiles : (ntiles + 1) >> 1;       // barrier iterations of the workgroup (= group 0's tiles)
+    const int t0 = grp * nhalf, t1 = KS == 1 ? ntiles : (grp == 0 ? nhalf : ntiles);      // this group's tiles
     auto issue_tile = [&](int t, int buf) {
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
@@ -406,7 +419,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 2 : 1) void attn2_kernel(A
             }
         }
     };
-    issue_tile(0, 0);
+    if (t0 < t1) issue_tile(t0, 0);
 
     // ---- Q fragments (B operand), scaled by scale*log2(e): lane holds Q[qrow][16ks + 8hh + j] ----
     h8 qf[C::NKS];
@@ -425,7 +438,7 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 2 : 1) void attn2_kernel(A
 #pragma unroll
     for (int ks = 0; ks < C::NKS; ++ks) {
         const int c = 2 * ks + hh;
-        kaddr[ks] = c < C::NCH ? l31 * C::ROWB + C::pos(c, l31) * 16 : C::CELLS + 16;
+        kaddr[ks] = gbase + (c < C::NCH ? l31 * C::ROWB + C::pos(c, l31) * 16 : C::CELLS + 16);
     }
     const int vq = (lane & 15) >> 2, vp = lane & 3, vg1 = (lane >> 4) & 1;
     int vaddr[C::NDB][2];
@@ -435,8 +448,8 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 2 : 1) void attn2_kernel(A
         for (int hi = 0; hi < 2; ++hi) {
             const int d = db * 32 + 16 * vg1 + 4 * vp;
             const int key = 8 * hi + 4 * hh + vq;
-            vaddr[db][hi] = d < D ? C::TILE + key * C::ROWB + C::pos(d >> 3, key) * 16 + (d & 7) * 2
-                                  : (d == D ? C::CELLS : C::CELLS + 8) + 8 * hi * C::ROWB;
+            vaddr[db][hi] = gbase + (d < D ? C::TILE + key * C::ROWB + C::pos(d >> 3, key) * 16 + (d & 7) * 2
+                                          : (d == D ? C::CELLS : C::CELLS + 8) + 8 * hi * C::ROWB);
         }
 
     f16v oacc[C::NDB];
@@ -446,11 +459,13 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 2 : 1) void attn2_kernel(A
         for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
     float m_run = 0.f, l_run = 0.f;
 
-    auto tile = [&](int t, auto buf_tag) {
+    auto tile = [&](int it, auto buf_tag) {
         constexpr int BUF = decltype(buf_tag)::value;
+        const int t = t0 + it;                // it: iteration of the workgroup; t: tile of this key group
         attn_wait_vmcnt<0>();                 // this wave's pieces of tile t have landed
         __builtin_amdgcn_s_barrier();         // everyone's have; everyone is done with the other buffer (tile t-1)
-        if (t + 1 < ntiles) issue_tile(t + 1, BUF ^ 1);
+        if (KS > 1 && t >= t1) return;        // group 1 of an odd tile count: one idle iteration (barrier only)
+        if (t + 1 < t1) issue_tile(t + 1, BUF ^ 1);
 
         // ---- S^T = K Q^T (MFOLD: minus the running max) ----
         f16v sacc[2];
@@ -486,9 +501,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 2 : 1) void attn2_kernel(A
         }
         const float grow = C::MFOLD ? mt : mt - m_run;          // how far this tile's max exceeds the running one
         float sub = C::MFOLD ? 0.f : m_run;
-        if (t == 0 || __any(grow > THR)) {
-            const float delta = t == 0 ? grow : fmaxf(grow, 0.f);
-            if (t != 0) {
+        if (it == 0 || __any(grow > THR)) {
+            const float delta = it == 0 ? grow : fmaxf(grow, 0.f);
+            if (it != 0) {
                 const float alpha = __builtin_amdgcn_exp2f(-delta);
                 l_run *= alpha;
 #pragma unroll
@@ -546,9 +561,34 @@ __global__ __launch_bounds__(64 * WAVES, WAVES == 8 ? 2 : 1) void attn2_kernel(A
         });
         if (!C::ONES) l_run += psum;
     };
-    for (int t = 0; t < ntiles; t += 2) {
-        tile(t, std::integral_constant<int, 0>{});
-        if (t + 1 < ntiles) tile(t + 1, std::integral_constant<int, 1>{});
+    for (int it = 0; it < nhalf; it += 2) {
+        tile(it, std::integral_constant<int, 0>{});
+        if (it + 1 < nhalf) tile(it + 1, std::integral_constant<int, 1>{});
+    }
+
+    if constexpr (KS > 1) {
+        // ---- merge the two key groups: group 1 -> LDS ([wave][register][lane] floats, over the tile buffers) -> group 0 ----
+        constexpr int NR = C::NDB * 16 + 2;
+        __syncthreads();                      // every wave is past its last fragment reads
+        float* xch = reinterpret_cast<float*>(smem_all) + wave * NR * 64 + lane;
+        if (grp == 1) {
+#pragma unroll
+            for (int i = 0; i < C::NDB; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xch[(i * 16 + r) * 64] = oacc[i][r];
+            xch[(C::NDB * 16) * 64] = t0 < t1 ? m_run : -1.0e30f;
+            xch[(C::NDB * 16 + 1) * 64] = l_run;
+        }
+        __syncthreads();
+        if (grp == 1) return;
+        const float m2 = xch[(C::NDB * 16) * 64], l2 = xch[(C::NDB * 16 + 1) * 64];
+        const float m = fmaxf(m_run, m2);
+        const float a1 = __builtin_amdgcn_exp2f(m_run - m), a2 = __builtin_amdgcn_exp2f(m2 - m);
+        l_run = l_run * a1 + l2 * a2;
+#pragma unroll
+        for (int i = 0; i < C::NDB; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[i][r] = oacc[i][r] * a1 + xch[(i * 16 + r) * 64] * a2;
     }
 
     // ---- epilogue: O[q][d] = O^T[d][q] / l ----
@@ -579,28 +619,40 @@ extern "C" int lcm_set_attention_impl(int impl) {
     return LCM_OK;
 }
 
-template <int D, int WAVES>
+template <int D, int WAVES, int KS = 1>
 static int launch_attn2_w(const AttnParams& p, hipStream_t s) {
     using C = Attn2Cfg<D>;
+    static_assert(KS * C::LDS_BYTES <= 160 * 1024 && (KS == 1 || 4 * WAVES * (C::NDB * 16 + 2) * 64 <= KS * C::LDS_BYTES), "attn2 LDS");
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn2_kernel<D, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn2_kernel<D, WAVES, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, KS * C::LDS_BYTES);
         attr_set = true;
     }
     const int nqb = (p.Sq + 32 * WAVES - 1) / (32 * WAVES);
-    char nm[32];
-    snprintf(nm, sizeof(nm), "attn2_kernel<%d, %d>", D, WAVES);
+    char nm[40];
+    if (KS == 1) snprintf(nm, sizeof(nm), "attn2_kernel<%d, %d>", D, WAVES);
+    else snprintf(nm, sizeof(nm), "attn2_kernel<%d, %d, %d>", D, WAVES, KS);
     lcm_prof_start(nm, s);
-    hipLaunchKernelGGL((attn2_kernel<D, WAVES>), dim3(nqb * p.B * p.heads), dim3(64 * WAVES), C::LDS_BYTES, s, p, nqb);
+    hipLaunchKernelGGL((attn2_kernel<D, WAVES, KS>), dim3(nqb * p.B * p.heads), dim3(64 * WAVES * KS), KS * C::LDS_BYTES, s, p, nqb);
     lcm_prof_stop(s);
     LCM_CHECK_LAUNCH("attention2");
     return LCM_OK;
 }
 
+static int g_attn2_ksplit = 1;    // 0: never split the keys of a query block (A/B switch; changes the bits of the >= 1024-key levels)
+extern "C" int lcm_set_attention_ksplit(int on) { g_attn2_ksplit = on ? 1 : 0; return LCM_OK; }
+
 template <int D>
 static int launch_attn2(const AttnParams& p, hipStream_t s) {
     // 256-row workgroups when they still give every CU two (the K/V tiles are staged once per workgroup), else 128-row ones
+    // >= 1024 keys: the key-split form (two groups of 4 waves over 128 query rows), whatever the batch -- the split changes the
+    // summation order, so it is keyed on the sequence length alone
     const long long wg8 = (long long)((p.Sq + 255) / 256) * p.B * p.heads;
+    if (g_attn2_ksplit && p.Sk >= 1024) {
+        // d = 40 fits 128 VGPRs: batched launches take 256 query rows x 2 key groups (16 waves, K/V staged once per 256 rows)
+        if constexpr (D == 40) if (g_attn_waves == 8 || (g_attn_waves == 0 && wg8 >= 512)) return launch_attn2_w<D, 8, 2>(p, s);
+        return launch_attn2_w<D, 4, 2>(p, s);
+    }
     const bool w8 = g_attn_waves == 8 || (g_attn_waves == 0 && wg8 >= 512);
     return w8 ? launch_attn2_w<D, 8>(p, s) : launch_attn2_w<D, 4>(p, s);
 }

@@ -70,6 +70,7 @@ _SIGS = {
     "lcm_set_seg_mode": [_i],
     "lcm_set_attention_waves": [_i],
     "lcm_set_attention_impl": [_i],
+    "lcm_set_attention_ksplit": [_i],
     "lcm_set_kernel_variant": [_i],
     "lcm_set_conv_impl": [_i],
     "lcm_set_persist_n": [_i],

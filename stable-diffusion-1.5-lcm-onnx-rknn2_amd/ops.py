@@ -442,6 +442,10 @@ def set_attention_impl(impl):
     _lib.check(_lib.load().lcm_set_attention_impl(int(impl)), "lcm_set_attention_impl")
 
 
+def set_attention_ksplit(on):
+    _lib.check(_lib.load().lcm_set_attention_ksplit(int(on)), "lcm_set_attention_ksplit")
+
+
 def set_seg_mode(mode):
     """0 auto, 1 always segmented accumulation, 2 always split + reduce (bit-identical; include/lcm_hip.h)."""
     _lib.check(_lib.load().lcm_set_seg_mode(int(mode)), "lcm_set_seg_mode")

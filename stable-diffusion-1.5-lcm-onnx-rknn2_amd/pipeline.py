@@ -169,6 +169,8 @@ class LcmHipPipeline:
             ops.set_persist_n(int(os.environ["LCM_PERSIST_N"]))
         if "LCM_HALO_PIPE" in os.environ:
             ops.set_halo_pipe_threshold(int(os.environ["LCM_HALO_PIPE"]))
+        if "LCM_ATTN_KSPLIT" in os.environ:          # 0: unsplit streaming attention at every length (changes the bits of the >= 1024-key levels)
+            ops.set_attention_ksplit(int(os.environ["LCM_ATTN_KSPLIT"]))
         if "LCM_KERNEL_VARIANT" in os.environ:
             ops.set_kernel_variant(int(os.environ["LCM_KERNEL_VARIANT"]))
 

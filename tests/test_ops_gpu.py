@@ -687,6 +687,33 @@ def test_attention_prescaled_q(heads, Sq, Sk, d):
     close(out, ref, rtol=6e-3, what=f"prescaled attention S{Sq}x{Sk} d{d}")
 
 
+@pytest.mark.parametrize("B,heads,S,d", [(1, 8, 1088, 40), (2, 8, 1030, 80), (1, 4, 1024, 64), (1, 2, 4096, 40), (1, 8, 2049, 40)])
+def test_attention_key_split(B, heads, S, d):
+    """>= 1024 keys: the keys of a query block are split over two wave groups and merged (odd tile counts: group 1 idles one
+    iteration; ragged last tile in group 1; a dominant key in either half).  Against torch SDPA in fp32, and against the
+    unsplit kernel (lcm_set_attention_ksplit(0)) -- same accuracy, different summation order."""
+    C = heads * d
+    qkv = rnd(B * S, 3 * C, seed=S)
+    qkv[S - 30, C:2 * C] = qkv[5, :C] * 3           # late key dominates query 5 (second group)
+    qkv[17, C:2 * C] = qkv[S - 9, :C] * 3           # early key dominates a late query (first group)
+    qh, kh, vh = (qkv[:, i * C:(i + 1) * C].float().reshape(B, S, heads, d).transpose(1, 2) for i in range(3))
+    ref = F.scaled_dot_product_attention(qh, kh, vh).transpose(1, 2).reshape(B * S, C)
+    t = qkv.to(DEV)
+    outs = []
+    try:
+        for on in (1, 0):
+            ops.set_attention_ksplit(on)
+            o = torch.empty(B * S, C, dtype=torch.float16, device=DEV)
+            ops.attention(t[:, :C], t[:, C:2 * C], t[:, 2 * C:], o, B, heads, S, S, d, ldq=3 * C, ldk=3 * C, ldv=3 * C, ldo=C)
+            outs.append(o)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_attention_ksplit(1)
+    close(outs[0], ref, rtol=6e-3, what=f"key-split attention S{S} d{d}")
+    close(outs[1], ref, rtol=6e-3, what=f"unsplit attention S{S} d{d}")
+    assert not torch.equal(outs[0], outs[1]) or S < 1024
+
+
 def test_attention_strided_qkv():
     """Fused QKV buffer: q/k/v are column slices of one [B*S, 3C] tensor."""
     B, heads, S, d = 2, 8, 256, 40
