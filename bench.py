@@ -130,7 +130,14 @@ def _pmc_counters(kernel_name):
     key = kernel_name.rstrip(">").strip()
     for k, v in tab.items():
         if k.rstrip(">").strip().startswith(key):
-            return {"mfma_busy_frac": v["mfma_busy_frac"], "hbm_gbs": v["hbm_gbs"], "effective_clock_ghz": v["effective_clock_ghz"],
+            clk = v.get("effective_clock_ghz")
+            if clk is not None and clk > 2.5 and v.get("mfma_busy_frac_at_2p1ghz") is not None:
+                # launches of a few microseconds: GRBM_GUI_ACTIVE also counts the dispatch around the kernel (an "effective clock"
+                # above the chip's 2.4 GHz), so the busy cycles are taken over the kernel's own duration at 2.1 GHz instead
+                return {"mfma_busy_frac": v["mfma_busy_frac_at_2p1ghz"], "hbm_gbs": v["hbm_gbs"], "effective_clock_ghz": None,
+                        "pmc_source": f"{v['source']} ({v['what']}): SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs over the kernel's duration x 2.1 GHz "
+                                      f"(GRBM_GUI_ACTIVE over-counts launches this short); (2 x FETCH_SIZE + WRITE_SIZE) / kernel time"}
+            return {"mfma_busy_frac": v["mfma_busy_frac"], "hbm_gbs": v["hbm_gbs"], "effective_clock_ghz": clk,
                     "pmc_source": f"{v['source']} ({v['what']}): SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs over GRBM_GUI_ACTIVE / 8 XCDs; "
                                   f"(2 x FETCH_SIZE + WRITE_SIZE) / kernel time"}
     return {"mfma_busy_frac": None, "hbm_gbs": None,
