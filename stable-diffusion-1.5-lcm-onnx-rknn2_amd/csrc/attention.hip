@@ -233,11 +233,10 @@ extern "C" int lcm_set_attention_waves(int waves) {
 template <int D, int WAVES>
 static int launch_attn_w(const AttnParams& p, hipStream_t s) {
     using C = AttnCfg<D>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static LcmDevOnce attr_once;
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<D, WAVES>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
-        attr_set = true;
     }
     dim3 grid((p.Sq + 32 * WAVES - 1) / (32 * WAVES), p.B * p.heads);
     char nm[32];
@@ -623,10 +622,9 @@ template <int D, int WAVES, int KS = 1>
 static int launch_attn2_w(const AttnParams& p, hipStream_t s) {
     using C = Attn2Cfg<D>;
     static_assert(KS * C::LDS_BYTES <= 160 * 1024 && (KS == 1 || 4 * WAVES * (C::NDB * 16 + 2) * 64 <= KS * C::LDS_BYTES), "attn2 LDS");
-    static bool attr_set = false;
-    if (!attr_set) {
+    static LcmDevOnce attr_once;
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn2_kernel<D, WAVES, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, KS * C::LDS_BYTES);
-        attr_set = true;
     }
     const int nqb = (p.Sq + 32 * WAVES - 1) / (32 * WAVES);
     char nm[40];
@@ -851,10 +849,9 @@ __global__ __launch_bounds__(256, 1) void attn_wide_kernel(AttnParams p) {
 template <int D, int TK>
 static int launch_attn_wide(const AttnParams& p, hipStream_t s) {
     constexpr int LDS = 2 * 2 * TK * (D * 2 + 32);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static LcmDevOnce attr_once;
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_wide_kernel<D, TK>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
     }
     dim3 grid((p.Sq + 63) / 64, p.B * p.heads);
     char nm[32];

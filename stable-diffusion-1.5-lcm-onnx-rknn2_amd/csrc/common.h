@@ -5,6 +5,21 @@
 #include <stdio.h>
 
 typedef _Float16 half_t;
+// hipFuncSetAttribute (the dynamic-LDS limit of a kernel) holds for the CURRENT device only: a process that drives several
+// GPUs (LCM_DEVICES=all: worker i on cuda:i) must set it once per device, not once per process.
+#include <atomic>
+struct LcmDevOnce {
+    std::atomic<unsigned long long> mask{0};
+    bool first() {
+        int d = 0;
+        (void)hipGetDevice(&d);
+        const unsigned long long bit = 1ull << (d & 63);
+        if (mask.load(std::memory_order_relaxed) & bit) return false;
+        mask.fetch_or(bit, std::memory_order_relaxed);
+        return true;
+    }
+};
+
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));

@@ -500,11 +500,10 @@ static void launch_halo(HaloParams& hp, hipStream_t s, int force) {     // force
         constexpr int WS = 3;
         constexpr int smem = 2 * HROWS_PAD * 128 + WS * TPS * BN * 128;
         static_assert(smem <= 160 * 1024, "halo ring exceeds LDS");
-        static bool attr_set = false;
-        if (!attr_set) {
+        static LcmDevOnce attr_once;
+        if (attr_once.first()) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_pipe_kernel<TH, TW, BN, WS, PH, TPS, 1>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-            attr_set = true;
         }
         char nm[80];
         snprintf(nm, sizeof(nm), "conv_halo_pipe_kernel<%d, %d, %d, %d, %d, %d, 1>", TH, TW, BN, WS, PH, TPS);
@@ -519,11 +518,10 @@ static void launch_halo(HaloParams& hp, hipStream_t s, int force) {     // force
         constexpr int WS = BN == 64 ? 3 : 2;
         constexpr int smem = 2 * HROWS_PAD * 128 + WS * TPS * BN * 128;
         static_assert(smem <= 160 * 1024, "row-step halo ring exceeds LDS");
-        static bool attr_set = false;
-        if (!attr_set) {
+        static LcmDevOnce attr_once;
+        if (attr_once.first()) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_pipe_kernel<TH, TW, BN, WS, PH, TPS>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-            attr_set = true;
         }
         char nm[64];
         snprintf(nm, sizeof(nm), "conv_halo_pipe_kernel<%d, %d, %d, %d, %d, %d>%s", TH, TW, BN, WS, PH, TPS, hp.g.splits > 1 ? " +splitk" : "");
@@ -535,11 +533,10 @@ static void launch_halo(HaloParams& hp, hipStream_t s, int force) {     // force
     if (!XFORM && force != 1 && (force == 2 || force == 3 || (long long)grid.x * grid.y < g_halo_pipe_below)) {
         constexpr int WS = 3;
         constexpr int smem = 2 * HROWS_PAD * 128 + WS * BN * 128;
-        static bool attr_set = false;
-        if (!attr_set) {
+        static LcmDevOnce attr_once;
+        if (attr_once.first()) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_pipe_kernel<TH, TW, BN, WS, PH, 1>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-            attr_set = true;
         }
         char nm[64];
         snprintf(nm, sizeof(nm), "conv_halo_pipe_kernel<%d, %d, %d, %d, %d, 1>%s", TH, TW, BN, WS, PH, hp.g.splits > 1 ? " +splitk" : "");

@@ -698,11 +698,10 @@ extern "C" int lcm_gemm_tile_config(int M, int N, int batch) {
 template <int BM, int BN, int MODE, int S, int LN = 0, int SEG = 0>
 static int launch_v2(IgemmParams& p, dim3 grid, hipStream_t s) {
     constexpr int smem = S * (BM + BN) * 128 + (LN ? 2 * BN * 4 : 0);       // LN: + this n-tile's ln_g | ln_c
-    static bool attr_set = false;
-    if (!attr_set) {
+    static LcmDevOnce attr_once;
+    if (attr_once.first()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<BM, BN, MODE, S, LN, SEG>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        attr_set = true;
     }
     char nm[64];
     snprintf(nm, sizeof(nm), "igemm2_kernel<%d, %d, %d, %d, %d, %d>%s", BM, BN, MODE, S, LN, SEG, p.splits > 1 ? " +splitk" : "");
@@ -753,11 +752,10 @@ static int launch_cfg(IgemmParams& p, int batch, int splits, int plan_variant, h
     }
     if (variant == 0) {
         const int smem = 2 * (BM + BN) * 128;
-        static bool attr_set = false;
-        if (!attr_set) {
+        static LcmDevOnce attr_once;
+        if (attr_once.first()) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, MODE, LN>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-            attr_set = true;
         }
         char nm[64];
         snprintf(nm, sizeof(nm), "igemm_kernel<%d, %d, %d, %d>%s", BM, BN, MODE, LN, p.splits > 1 ? " +splitk" : "");
