@@ -352,7 +352,10 @@ __device__ __forceinline__ h8 attn2_read_b128(int addr) {
 // block -- 64 tiles at S = 4096, each a barrier, two MFMA phases and an exp2 phase that nothing overlaps at one wave per SIMD
 // (batch 1: 256 workgroups) -- halves, and every SIMD holds two waves whose MFMA and VALU phases interleave.
 template <int D, int WAVES, int KS>
-__global__ __launch_bounds__(64 * WAVES * KS, (WAVES * KS == 8) ? 2 : 1) void attn2_kernel(AttnParams p, int nqb) {      // 16 waves: one workgroup per CU, <= 128 VGPRs
+// (second launch-bound = waves per SIMD the register budget must allow.  d = 64 with the key split: 4, i.e. <= 128 VGPRs, so that
+// two 8-wave workgroups share a CU -- at 142 VGPRs one workgroup per CU left the 320 workgroups of SDXL's 4096-token level in
+// two rounds)
+__global__ __launch_bounds__(64 * WAVES * KS, (WAVES * KS == 8) ? (D == 64 && KS == 2 ? 4 : 2) : 1) void attn2_kernel(AttnParams p, int nqb) {
     using C = Attn2Cfg<D>;
     constexpr int NP = (2 * C::NCH + WAVES - 1) / WAVES;        // DMA pieces per wave per tile
     constexpr float THR = 8.0f;                                   // deferred rescale: P <= 2^THR (fp16: no precision cost)
