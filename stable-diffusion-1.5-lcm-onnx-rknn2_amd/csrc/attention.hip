@@ -333,6 +333,18 @@ struct Attn2Cfg {
         else if constexpr (D == 80) { const int v = c + 3 * ((r >> 3) & 1); return v >= NCH ? v - NCH : v; }
         else return c;
     }
+    // V tile only, d = 40: LDS row of key r.  The transposed fragment read (ds_read_b64_tr_b16) takes 4 consecutive keys per
+    // 32-lane group, 64 bytes of each; with 80-byte rows keys k and k+3 share banks (240 + 64 wraps past 256): 22 % of the
+    // LDS cycles of the kernel were bank conflicts (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE).  Keys 4a + b go to row
+    // 16 (a / 4) + 4 b + a % 4: the 4 keys of a read sit 320 bytes = 64 mod 256 apart -- four disjoint 64-byte windows.
+    static __device__ __forceinline__ int vrow(int r) {
+        if constexpr (D == 40) { const int a = r >> 2, b = r & 3; return 16 * (a >> 2) + 4 * b + (a & 3); }
+        else return r;
+    }
+    static __device__ __forceinline__ int vkey(int row) {        // inverse of vrow
+        if constexpr (D == 40) { const int q = row >> 4, rem = row & 15; return 4 * (4 * q + (rem & 3)) + (rem >> 2); }
+        else return row;
+    }
     static __device__ __forceinline__ int unpos(int p, int r) {
         if constexpr (D == 64) return pos(p, r);
         else if constexpr (D == 80) { const int v = p - 3 * ((r >> 3) & 1); return v < 0 ? v + NCH : v; }
@@ -397,9 +409,10 @@ __global__ __launch_bounds__(64 * WAVES * KS, (WAVES * KS == 8) ? (D == 64 && KS
         const int i = wave + j * WAVES;
         const int pi = i >= C::NCH ? i - C::NCH : i;
         const int pidx = pi * 64 + lane;
-        const int row = pidx / C::NCH, ps = pidx - row * C::NCH;
+        const int lrow = pidx / C::NCH, ps = pidx - lrow * C::NCH;       // LDS row this lane fills
+        const int row = i >= C::NCH ? C::vkey(lrow) : lrow;                 // the key that lives there
         pc_row[j] = row;
-        pc_off[j] = row * (i >= C::NCH ? p.ldv : p.ldk) + C::unpos(ps, row) * 8;
+        pc_off[j] = row * (i >= C::NCH ? p.ldv : p.ldk) + C::unpos(ps, lrow) * 8;
     }
     const int ntiles = (p.Sk + 63) >> 6;
     const int nhalf = KS == 1 ? ntiles : (ntiles + 1) >> 1;       // barrier iterations of the workgroup (= group 0's tiles)
@@ -450,7 +463,7 @@ __global__ __launch_bounds__(64 * WAVES * KS, (WAVES * KS == 8) ? (D == 64 && KS
         for (int hi = 0; hi < 2; ++hi) {
             const int d = db * 32 + 16 * vg1 + 4 * vp;
             const int key = 8 * hi + 4 * hh + vq;
-            vaddr[db][hi] = gbase + (d < D ? C::TILE + key * C::ROWB + C::pos(d >> 3, key) * 16 + (d & 7) * 2
+            vaddr[db][hi] = gbase + (d < D ? C::TILE + C::vrow(key) * C::ROWB + C::pos(d >> 3, C::vrow(key)) * 16 + (d & 7) * 2
                                           : (d == D ? C::CELLS : C::CELLS + 8) + 8 * hi * C::ROWB);
         }
 

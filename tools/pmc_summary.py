@@ -10,8 +10,10 @@ import json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TAGS = {"gemm64_b1": "gemm M4096 N320 K320 (batch-1 transformer GEMM, 64x64 tile, 4-stage ring)",
         "convgn_b8": "GroupNorm-fused conv3x3 8 x 512^2 x 128 -> 128 (AutoencoderKL top level, batch 8)",
-        "attn2_b8": "self-attention 8 images x 8 heads, S = 4096, d = 40 (UNet level 0, batch 8)",
-        "attn2_b1": "self-attention 1 image x 8 heads, S = 4096, d = 40 (UNet level 0, batch 1)"}
+        "attn2_b8": "self-attention 8 images x 8 heads, S = 4096, d = 40 (UNet level 0, batch 8; key-split form, 16 waves)",
+        "attn2_b1": "self-attention 1 image x 8 heads, S = 4096, d = 40 (UNet level 0, batch 1; key-split form, 8 waves)",
+        "attn2_b8_unsplit": "the same launch with lcm_set_attention_ksplit(0) (first half of round 3)",
+        "attn2_b1_unsplit": "the same launch with lcm_set_attention_ksplit(0) (first half of round 3)"}
 out = {}
 for tag, what in TAGS.items():
     p = os.path.join(ROOT, "profiles", f"r03_pmc_{tag}.txt")
