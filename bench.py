@@ -217,6 +217,13 @@ def main():
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
+    # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a five-line version banner to stdout when
+    # its first communicator comes up -- on every rank): keep the real stdout aside for the line and send everything else that
+    # lands on fd 1 to stderr.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     import sdlcm_amd  # noqa: F401
@@ -266,6 +273,7 @@ def main():
 
     bcast_ms = {}
     encoders = {}
+    comm_stream = torch.cuda.Stream(device=dev) if dist is not None else None      # collectives only; never captured
 
     def prompt_embeddings(pl, count):
         """What north_star describes: the rank that owns the prompt encoder (rank 0) runs it -- ClipTextHip on the HIP kernels,
@@ -295,16 +303,21 @@ def main():
             if dist is not None:
                 from sdlcm_amd.distributed import broadcast_embeddings
                 P.lane.stream.synchronize()
-                for rep in range(2):                  # first call sets the communicator up; the second is the exchange itself
-                    dist.barrier()
-                    torch.cuda.synchronize()
-                    tb = time.perf_counter()
-                    if backend == "nccl":             # the one exchange step: 118 KB per prompt over xGMI
-                        got = broadcast_embeddings(allpe, world * Bx, 77, pl.unet.ctx_dim, dev)
-                    else:
-                        got = broadcast_embeddings(allpe.cpu() if allpe is not None else None, world * Bx, 77, pl.unet.ctx_dim, "cpu").to(dev)
-                    torch.cuda.synchronize()
-                    bcast_ms[Bx] = (time.perf_counter() - tb) * 1e3
+                # Collectives run on a stream of their own, never on a lane's: ProcessGroupNCCL's watchdog thread polls the
+                # events of recent work, and on HIP an event query fails ("operation not permitted on an event last recorded
+                # in a capturing stream") once the stream it was recorded on is being captured -- which the lane's stream is,
+                # a few seconds later (seen once at world size 1: the process group's watchdog took the process down)
+                with torch.cuda.stream(comm_stream):
+                    for rep in range(2):              # first call sets the communicator up; the second is the exchange itself
+                        dist.barrier()
+                        torch.cuda.synchronize()
+                        tb = time.perf_counter()
+                        if backend == "nccl":         # the one exchange step: 118 KB per prompt over xGMI
+                            got = broadcast_embeddings(allpe, world * Bx, 77, pl.unet.ctx_dim, dev)
+                        else:
+                            got = broadcast_embeddings(allpe.cpu() if allpe is not None else None, world * Bx, 77, pl.unet.ctx_dim, "cpu").to(dev)
+                        torch.cuda.synchronize()
+                        bcast_ms[Bx] = (time.perf_counter() - tb) * 1e3
                 allpe = got
             P.ehs.copy_(allpe[rank * Bx:(rank + 1) * Bx].reshape(Bx * 77, pl.unet.ctx_dim))
             if pl.unet.has_added:      # SDXL: pooled text embedding + size/crop ids
@@ -344,13 +357,17 @@ def main():
         torch.cuda.synchronize()
         return time.perf_counter() - t0, K * len(Ps)
 
+    def barrier():
+        if dist is not None:
+            with torch.cuda.stream(comm_stream):      # see prime(): never on a stream that gets captured
+                dist.barrier()
+
     def timed(P, K, W):
         with torch.cuda.stream(P.lane.stream):
             for _ in range(W):
                 P.graph.launch()
             torch.cuda.synchronize()
-            if dist is not None:
-                dist.barrier()
+            barrier()
             torch.cuda.synchronize()
             evs = [torch.cuda.Event(enable_timing=True) for _ in range(K + 1)]
             t0 = time.perf_counter()
@@ -359,8 +376,7 @@ def main():
                 P.graph.launch()
                 evs[i + 1].record()
             torch.cuda.synchronize()
-            if dist is not None:
-                dist.barrier()
+            barrier()
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
         lat = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(K))
@@ -459,8 +475,10 @@ def main():
                                   "workload": "SDXL-base architecture 1024x1024, 30 steps, batch 1, guidance 1.0 (no CFG: UNet batch 1), fp16 "
                                               "VAE with residual-stream rescaling (BASELINE configs[4]; 213 TFLOP per image, SURVEY 8d)"}
             xl.close()
+    sys.stdout.flush()
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
+    os.close(real_stdout)
     if dist is not None:
         dist.destroy_process_group()
 

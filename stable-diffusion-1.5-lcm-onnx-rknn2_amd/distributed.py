@@ -22,7 +22,10 @@ def shard_bounds(n: int, world: int, rank: int) -> tuple[int, int]:
 
 
 def broadcast_embeddings(embeds, n: int, seq: int, dim: int, device, src: int = 0, group=None):
-    """Rank ``src`` passes ``embeds`` [n,seq,dim]; every rank gets the full fp16 tensor on ``device``."""
+    """Rank ``src`` passes ``embeds`` [n,seq,dim]; every rank gets the full fp16 tensor on ``device``.
+    Call it on a stream that is never captured into a hipGraph (not a pipeline lane's): the process group's watchdog thread
+    polls the events of recent collectives, and on HIP querying an event fails once its stream is being captured.
+    """
     if dist.get_rank(group) == src:
         t = torch.as_tensor(embeds).to(device=device, dtype=torch.float16).contiguous()
         assert tuple(t.shape) == (n, seq, dim)
