@@ -439,6 +439,12 @@ def main():
                                     "pipeline_tflops": round(fl_img * 8 / (dt8 / k8) / 1e12, 1),
                                     "workload": "same, batch 8 per GPU (BASELINE configs[2] per-GPU shard)",
                                     "roofline": roofline_leg(pipe, P8, 1.0, dt8 / k8 * 1e3)}
+            # the same batch-8 pass with TWO in flight (16 requests on the GPU, two lanes): the saturated serving mode of the
+            # worker's micro-batcher (backends/batching.py: a full batch waiting behind a running pass goes to the second lane)
+            P8b = prime(8, lane=1)
+            dtl8, npass8 = timed_lanes([P8, P8b], k8, 1)
+            line["extra_batch8_two_lanes"] = {"images_per_s": round(8 * npass8 / dtl8, 2), "ms_per_pass_per_lane": round(dtl8 / k8 * 1e3, 2),
+                                              "workload": "two batch-8 passes in flight on two lanes (16 requests on one GPU); never `value`"}
         if not args.no_extra and B == 1 and args.model == "sd15":
             P1 = prime(1, lane=1)
             dtl, npass = timed_lanes([P, P1], args.steps, 2)

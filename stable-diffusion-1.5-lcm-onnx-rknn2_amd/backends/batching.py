@@ -35,9 +35,12 @@ class MicroBatcher:
         its two-argument form."""
         self.run_batch = run_batch
         self.lanes = max(1, int(lanes))
-        # Lanes beyond the first serve LOW load only: with up to `lane_max_waiting` jobs waiting a second pass in flight
-        # beats batching (two batch-1 passes overlap to ~1.4x the time of one), with more waiting the first lane's next
-        # batched pass is the better use of the GPU (batch 4 / 8 passes already fill it; two of them just share it)
+        # Lanes beyond the first serve the two ENDS of the load range (tools/lanes_sweep.py: images/s @ latency with the same
+        # number of requests in flight -- 2: 72 @ 28 ms on two lanes = 75 @ 27 as one batch of 2; 4: 97 @ 41 either way;
+        # 8: 114 @ 70 as 4 + 4 against 116 @ 69 as one batch of 8; 16: 127 @ 126 as 8 + 8 on two lanes against 116 one after
+        # the other).  With up to `lane_max_waiting` jobs waiting a second pass in flight is as good as batching them and
+        # starts at once; in between, lane 0's next (larger) batched pass is the better use of the GPU; with a FULL batch
+        # waiting behind a running pass the second lane takes it
         self.lane_max_waiting = 2
         self._lane0_busy = False                    # lane 0 is inside run_batch (a pass, a first-use tune / capture, a style wait)
         self._lane0_since = 0.0
@@ -89,7 +92,12 @@ class MicroBatcher:
                     # (multi-second first-use tune / graph capture, waiting for a style re-merge): then serve.  Woken by
                     # lane 0's notify when it comes back for work, not by polling.
                     stalled = self._lane0_busy and time.monotonic() - self._lane0_since > self.lane0_stall_s
-                    if not stalled:
+                    # ... or a FULL batch is already waiting behind lane 0's pass: two largest-size passes in flight finish
+                    # 9 % more images per second than one after the other (126.7 against 116.4 images/s at batch 8,
+                    # tools/lanes_sweep.py), and the waiting batch is done sooner than if it queued behind the running one
+                    head = self._q[0][0]
+                    full = sum(1 for e in self._q if e[0] == head) >= self.max_batch
+                    if not stalled and not full:
                         self._cv.wait(self.lane0_stall_s)
                         continue
                 if self.window > 0:

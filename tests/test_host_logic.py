@@ -504,6 +504,35 @@ def test_second_lane_serves_when_lane0_is_stuck():
     mb.close()
 
 
+def test_second_lane_takes_a_full_batch_waiting_behind_lane0():
+    """With more than a couple of jobs waiting the second lane normally leaves them to lane 0's next batched pass -- unless a
+    FULL batch is already waiting while lane 0 is inside a pass: then it runs that batch concurrently."""
+    import threading, time
+    from sdlcm_amd.backends.batching import MicroBatcher
+    gate, served = threading.Event(), []
+
+    def run(key, items, lane):
+        if lane == 0:
+            gate.wait(10)
+        served.append((lane, len(items)))
+        return list(items)
+
+    mb = MicroBatcher(run, max_batch=8, lanes=2)
+    mb.lane0_stall_s = 5.0                           # the stall rule must not be what lets lane 1 in
+    first = mb.submit("k", -1)
+    time.sleep(0.05)
+    assert mb._lane0_busy
+    few = [mb.submit("k", i) for i in range(5)]      # 5 waiting: not a full batch -> lane 1 defers
+    time.sleep(0.3)
+    assert not served
+    more = [mb.submit("k", 5 + i) for i in range(3)] # 8 waiting: lane 1 takes them as one batch of 8 while lane 0 is still busy
+    assert [f.result(5) for f in few + more] == list(range(8))
+    assert served == [(1, 8)] and not first.done()
+    gate.set()
+    assert first.result(5) == -1
+    mb.close()
+
+
 def test_lone_caller_stays_on_lane0():
     """One caller at a time never reaches the other lanes (each would allocate its own workspace, buffers and graphs on first
     use): lane k > 0 only serves while lane 0 is inside a pass.  Two concurrent callers do use both."""
