@@ -240,7 +240,7 @@ int lcm_set_attention_waves(int waves);
  * everything else.  Which kernel runs is a function of (d, Sk, causal) only -- never of B -- so a request's bits do not depend
  * on the batch; the two kernels differ in rounding (Q scaling in fp16, deferred max). */
 int lcm_set_attention_impl(int impl);
-/* 1 (default): self-attention over >= 1024 keys splits the keys of a query block over two wave groups of the workgroup
+/* 1 (default): self-attention over 1024..4096 keys splits the keys of a query block over two wave groups of the workgroup
  * (merged at the end; keyed on the sequence length alone, so batch-invariant); 0: never (A/B switch, changes those bits). */
 int lcm_set_attention_ksplit(int on);
 /* causal != 0: keys after the query are masked (CLIPTextModel's causal attention mask, transformers; the text

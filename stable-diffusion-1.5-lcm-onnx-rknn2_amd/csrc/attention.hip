@@ -357,7 +357,7 @@ __device__ __forceinline__ h8 attn2_read_b128(int addr) {
     return *reinterpret_cast<const __attribute__((address_space(3))) h8*>((size_t)(unsigned)(addr + OFF));
 }
 
-// KS = 2 (sequences of >= 1024 keys -- a property of the image, so a request computes the same bits at any batch size): the
+// KS = 2 (sequences of 1024..4096 keys -- a property of the image, so a request computes the same bits at any batch size): the
 // keys of a query block are split over TWO groups of WAVES waves, tiles [0, ceil(n/2)) and [ceil(n/2), n); each group streams
 // its tiles through its own double buffer and keeps its own (m, l, O^T); at the end group 1 hands its state to group 0 through
 // LDS and group 0 merges (O = O1 2^(m1-m) + O2 2^(m2-m), the row sums likewise) and stores.  The dependent chain of a query
@@ -659,10 +659,10 @@ extern "C" int lcm_set_attention_ksplit(int on) { g_attn2_ksplit = on ? 1 : 0; r
 template <int D>
 static int launch_attn2(const AttnParams& p, hipStream_t s) {
     // 256-row workgroups when they still give every CU two (the K/V tiles are staged once per workgroup), else 128-row ones
-    // >= 1024 keys: the key-split form (two groups of 4 waves over 128 query rows), whatever the batch -- the split changes the
+    // 1024..4096 keys: the key-split form (two groups of 4 waves over 128 query rows), whatever the batch -- the split changes the
     // summation order, so it is keyed on the sequence length alone
     const long long wg8 = (long long)((p.Sq + 255) / 256) * p.B * p.heads;
-    if (g_attn2_ksplit && p.Sk >= 1024) {
+    if (g_attn2_ksplit && p.Sk >= 1024 && p.Sk <= 4096) {      // beyond 4096 keys a query block's chain is long enough to amortise itself: 9216 keys measured 2.5-6 % slower split
         // d = 40 fits 128 VGPRs: batched launches take 256 query rows x 2 key groups (16 waves, K/V staged once per 256 rows)
         if constexpr (D == 40) if (g_attn_waves == 8 || (g_attn_waves == 0 && wg8 >= 512)) return launch_attn2_w<D, 8, 2>(p, s);
         return launch_attn2_w<D, 4, 2>(p, s);

@@ -689,7 +689,7 @@ def test_attention_prescaled_q(heads, Sq, Sk, d):
 
 @pytest.mark.parametrize("B,heads,S,d", [(1, 8, 1088, 40), (2, 8, 1030, 80), (1, 4, 1024, 64), (1, 2, 4096, 40), (1, 8, 2049, 40)])
 def test_attention_key_split(B, heads, S, d):
-    """>= 1024 keys: the keys of a query block are split over two wave groups and merged (odd tile counts: group 1 idles one
+    """1024..4096 keys: the keys of a query block are split over two wave groups and merged (odd tile counts: group 1 idles one
     iteration; ragged last tile in group 1; a dominant key in either half).  Against torch SDPA in fp32, and against the
     unsplit kernel (lcm_set_attention_ksplit(0)) -- same accuracy, different summation order."""
     C = heads * d

@@ -9,7 +9,8 @@ import sdlcm_amd  # noqa
 from sdlcm_amd import ops
 
 DEV = "cuda"
-for (B, heads, S, d) in ((1, 8, 4096, 40), (8, 8, 4096, 40), (1, 8, 1024, 80), (8, 8, 1024, 80), (1, 20, 1024, 64), (1, 10, 4096, 64), (1, 8, 1088, 40), (2, 8, 1030, 80)):
+SHAPES = ((1, 8, 9216, 40), (8, 8, 9216, 40), (1, 8, 2304, 80), (8, 8, 2304, 80), (1, 10, 16384, 64)) if len(sys.argv) > 1 and sys.argv[1] == 'big' else None
+for (B, heads, S, d) in SHAPES or ((1, 8, 4096, 40), (8, 8, 4096, 40), (1, 8, 1024, 80), (8, 8, 1024, 80), (1, 20, 1024, 64), (1, 10, 4096, 64), (1, 8, 1088, 40), (2, 8, 1030, 80)):
     C = heads * d
     g = torch.Generator().manual_seed(S + d)
     qkv = torch.randn(B * S, 3 * C, generator=g).half()
