@@ -192,6 +192,23 @@ def spawn_command(gpus, argv, env):
             "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
 
 
+def claim_stdout():
+    """Keep the process's real stdout for the ONE JSON line and point fd 1 at stderr for everything else (Python prints and
+    C-level writes alike: RCCL's version banner, library chatter).  -> the saved descriptor for emit_line."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    return saved
+
+
+def emit_line(saved_fd, line):
+    """Write the JSON line (None: nothing -- ranks other than 0) to the descriptor claim_stdout() saved, and release it."""
+    sys.stdout.flush()
+    if line is not None:
+        os.write(saved_fd, (json.dumps(line) + "\n").encode())
+    os.close(saved_fd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -220,9 +237,7 @@ def main():
     # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a five-line version banner to stdout when
     # its first communicator comes up -- on every rank): keep the real stdout aside for the line and send everything else that
     # lands on fd 1 to stderr.
-    sys.stdout.flush()
-    real_stdout = os.dup(1)
-    os.dup2(2, 1)
+    real_stdout = claim_stdout()
 
     import numpy as np
     import torch
@@ -481,10 +496,7 @@ def main():
                                   "workload": "SDXL-base architecture 1024x1024, 30 steps, batch 1, guidance 1.0 (no CFG: UNet batch 1), fp16 "
                                               "VAE with residual-stream rescaling (BASELINE configs[4]; 213 TFLOP per image, SURVEY 8d)"}
             xl.close()
-    sys.stdout.flush()
-    if rank == 0:
-        os.write(real_stdout, (json.dumps(line) + "\n").encode())
-    os.close(real_stdout)
+    emit_line(real_stdout, line if rank == 0 else None)
     if dist is not None:
         dist.destroy_process_group()
 

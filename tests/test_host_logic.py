@@ -533,6 +533,23 @@ def test_second_lane_takes_a_full_batch_waiting_behind_lane0():
     mb.close()
 
 
+def test_bench_keeps_stdout_for_one_json_line():
+    """bench.py's contract is ONE JSON line on stdout; RCCL prints its version banner to stdout at communicator setup.  After
+    claim_stdout() everything written to fd 1 -- Python prints and C-level writes -- lands on stderr; emit_line() alone reaches
+    the real stdout."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import os, sys; sys.path.insert(0, %r); import bench\n"
+            "fd = bench.claim_stdout()\n"
+            "print('python chatter'); os.write(1, b'C-level banner\\n'); os.system('echo child chatter')\n"
+            "bench.emit_line(fd, {'metric': 'm', 'value': 1.5})\n" % root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.count("\n") == 1 and json.loads(r.stdout) == {"metric": "m", "value": 1.5}
+    for chatter in ("python chatter", "C-level banner", "child chatter"):
+        assert chatter in r.stderr
+
+
 def test_lone_caller_stays_on_lane0():
     """One caller at a time never reaches the other lanes (each would allocate its own workspace, buffers and graphs on first
     use): lane k > 0 only serves while lane 0 is inside a pass.  Two concurrent callers do use both."""
