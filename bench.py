@@ -173,6 +173,76 @@ def _pmc_traffic(kernel_name, batch):
         f"{e['WRITE_SIZE']:.0f} KB, averaged over {e['n_FETCH_SIZE']} launches of this kernel in an eager pass (separate --pmc runs)")
 
 
+def worker_leg(n_clients=16, n_requests=128, lone_requests=24):
+    """Through the reference's caller shape: ONE consumer thread takes jobs from a bounded queue and blocks in
+    ``worker.run_job`` (backends/worker_pool.py:294-341; here tools/minipool.MiniPool, replayed against a recording of the real
+    pool by the CPU tests).  Everything ``run_job`` does is inside the measurement: tokenise + CLIP encode, noise draw + H2D,
+    the sampler, RGB8 D2H, PNG.  (a) one closed-loop client: run_job latency; (b) `n_clients` closed-loop clients: the queue
+    behind the running job is drained into batched passes (HipLcmWorker._drain)."""
+    import statistics
+    import threading
+    from types import SimpleNamespace
+    from tools import minipool
+    from sdlcm_amd.backends.worker_factory import create_hip_worker
+    old = {k: os.environ.get(k) for k in ("MODEL", "MODEL_ROOT")}
+    os.environ["MODEL"] = "synthetic"
+    os.environ.setdefault("MODEL_ROOT", "/nonexistent")
+    w = create_hip_worker(worker_id=0)
+    pool = minipool.MiniPool(lambda worker_id: w, {"m": "synthetic"}, "m", queue_max=64)
+    w.bind_queue(pool.q)
+
+    def req(i):
+        return SimpleNamespace(prompt=f"benchmark prompt number {i} a lighthouse at dusk", size="512x512", num_inference_steps=4,
+                               guidance_scale=1.0, seed=1000 + i, style_lora=None)
+
+    def closed_loop(clients, total):
+        lat, lock, nxt = [], threading.Lock(), [0]
+
+        def client():
+            while True:
+                with lock:
+                    i = nxt[0]
+                    nxt[0] += 1
+                if i >= total:
+                    return
+                t0 = time.perf_counter()
+                png, seed = pool.submit_job(minipool.GenerationJob(req=req(i))).result(timeout=600)
+                assert png[:8] == b"\x89PNG\r\n\x1a\n" and seed == 1000 + i
+                with lock:
+                    lat.append(time.perf_counter() - t0)
+        th = [threading.Thread(target=client) for _ in range(clients)]
+        t0 = time.perf_counter()
+        [t.start() for t in th]
+        [t.join() for t in th]
+        return time.perf_counter() - t0, sorted(lat)
+
+    try:
+        closed_loop(1, 3)                                   # batch-1 plan: capture
+        closed_loop(n_clients, 5 * n_clients)               # batched plans on both lanes: first-use capture
+        dt1, lat1 = closed_loop(1, lone_requests)
+        nb0 = len(w._engine.batcher.batches)
+        dtn, latn = closed_loop(n_clients, n_requests)
+        sizes = w._engine.batcher.batches[nb0:]
+        return {"workload": f"run_job through a single-consumer pool-shaped loop (tools/minipool.py), 512x512 4 steps, PNG included; "
+                            f"synthetic weights; {n_clients} closed-loop clients / 1 client",
+                "images_per_s": round(n_requests / dtn, 2), "clients": n_clients, "requests": n_requests,
+                "latency_p50_ms": round(statistics.median(latn) * 1e3, 2), "latency_p95_ms": round(latn[int(0.95 * (len(latn) - 1))] * 1e3, 2),
+                "passes": len(sizes), "mean_batch": round(sum(sizes) / max(1, len(sizes)), 2),
+                "batch_histogram": {str(k): sizes.count(k) for k in sorted(set(sizes))},
+                "lone_client": {"images_per_s": round(lone_requests / dt1, 2), "run_job_p50_ms": round(statistics.median(lat1) * 1e3, 2),
+                                "run_job_p95_ms": round(lat1[int(0.95 * (len(lat1) - 1))] * 1e3, 2)}}
+    finally:
+        w.bind_queue(None)
+        pool._worker = None
+        pool.shutdown()
+        w.close()
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 def spawn_command(gpus, argv, env):
     """`python bench.py --gpus N` run by hand (no torchrun environment): the command that launches N fresh ranks, one per
     GPU.  None when this process already IS a rank (RANK / WORLD_SIZE set by torch.distributed.run) or N == 1.  A
@@ -288,7 +358,8 @@ def main():
 
     bcast_ms = {}
     encoders = {}
-    comm_stream = torch.cuda.Stream(device=dev) if dist is not None else None      # collectives only; never captured
+    if dist is not None:
+        from sdlcm_amd.distributed import comm_stream       # collectives only ever run on that module's own never-captured stream
 
     def prompt_embeddings(pl, count):
         """What north_star describes: the rank that owns the prompt encoder (rank 0) runs it -- ClipTextHip on the HIP kernels,
@@ -322,7 +393,7 @@ def main():
                 # events of recent work, and on HIP an event query fails ("operation not permitted on an event last recorded
                 # in a capturing stream") once the stream it was recorded on is being captured -- which the lane's stream is,
                 # a few seconds later (seen once at world size 1: the process group's watchdog took the process down)
-                with torch.cuda.stream(comm_stream):
+                with comm_stream(dev if backend == "nccl" else "cpu"):
                     for rep in range(2):              # first call sets the communicator up; the second is the exchange itself
                         dist.barrier()
                         torch.cuda.synchronize()
@@ -374,7 +445,7 @@ def main():
 
     def barrier():
         if dist is not None:
-            with torch.cuda.stream(comm_stream):      # see prime(): never on a stream that gets captured
+            with comm_stream(dev if backend == "nccl" else "cpu"):      # see prime(): never on a stream that gets captured
                 dist.barrier()
 
     def timed(P, K, W):
@@ -401,12 +472,13 @@ def main():
     dt, p50 = timed(P, args.steps, args.warmup)
     per_rank = [round(B * args.steps / dt, 3)]
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        allt = [torch.zeros_like(t) for _ in range(world)]
-        dist.all_gather(allt, t)
-        per_rank = [round(B * args.steps / float(x.item()), 3) for x in allt]
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        with comm_stream(dev if backend == "nccl" else "cpu"):
+            t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            allt = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(allt, t)
+            per_rank = [round(B * args.steps / float(x.item()), 3) for x in allt]
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
     images = world * B * args.steps
     line = {
         "metric": f"{S}x{S} {n}-step LCM images/sec", "value": round(images / dt, 3), "unit": "images/s",
@@ -439,6 +511,24 @@ def main():
         full = run_sharded(_gen, pe_all, [5000 + i for i in range(nreq)], cdev, gather_to=0)
         if rank == 0:
             line["exchange"]["sharded_check"] = {"requests": nreq, "gathered": list(full.shape), "ok": bool(full.shape[0] == nreq and full.any())}
+    if world > 1 and not args.no_extra and B == 1 and args.model == "sd15":
+        # BASELINE configs[2] itself: 8 requests per GPU in one batched pass on EVERY rank (64 requests on 8 GPUs); `value`
+        # stays the batch-1-per-GPU workload so that the N = 1 line is comparable
+        P8 = prime(8)
+        k8 = max(3, args.steps // 4)
+        dt8, _ = timed(P8, k8, 1)
+        with comm_stream(dev if backend == "nccl" else "cpu"):
+            t8 = torch.tensor([dt8], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            all8 = [torch.zeros_like(t8) for _ in range(world)]
+            dist.all_gather(all8, t8)
+            dist.all_reduce(t8, op=dist.ReduceOp.MAX)
+            torch.cuda.synchronize()
+        line["extra_batch8"] = {"images_per_s": round(world * 8 * k8 / float(t8.item()), 2), "ms_per_step": round(float(t8.item()) / k8 * 1e3, 2),
+                                "per_rank_images_per_s": [round(8 * k8 / float(x.item()), 2) for x in all8],
+                                "pipeline_tflops": round(5.74e12 * world * 8 / (float(t8.item()) / k8) / 1e12, 1),
+                                "global_batch": world * 8, "exchange_ms": round(bcast_ms.get(8, 0.0), 3),
+                                "workload": f"BASELINE configs[2]: {world * 8} requests, 8 per GPU in one batched pass on each of {world} GPUs "
+                                            f"(aggregate over ranks, max-over-ranks time)"}
     if rank == 0 and world == 1 and not args.no_roofline:
         line["roofline"] = roofline_leg(pipe, P, 1.0, dt / args.steps * 1e3)
         if args.model == "sdxl":
@@ -470,11 +560,12 @@ def main():
             # BASELINE configs[3]: 768x768, 8 steps, batch 8 on one GPU (3 timed passes)
             P3 = prime(8, hh=96, ww=96, nn=8)
             dt3, _ = timed(P3, 3, 1)
-            fl3 = 5.74e12 * (768 * 768) / (512 * 512) * 8 / 4
             line["extra_768_b8"] = {"images_per_s": round(8 * 3 / dt3, 3), "ms_per_step": round(dt3 / 3 * 1e3, 2),
                                     "pipeline_tflops": round(22.95e12 * 8 / (dt3 / 3) / 1e12, 1),
                                     "workload": "SD1.5 LCM 768x768, 8 steps, batch 8 (BASELINE configs[3]; 22.95 TFLOP per image, SURVEY 8d)"}
-            del fl3
+            del P3
+        if not args.no_extra and B == 1 and args.model == "sd15" and S == 512 and os.environ.get("LCM_BENCH_WORKER", "1") != "0":
+            line["extra_worker"] = worker_leg()
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(host_threads())
         if not args.no_extra and B == 1 and args.model == "sd15" and S == 512 and os.environ.get("LCM_BENCH_SDXL", "1") != "0":

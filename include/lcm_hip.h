@@ -70,9 +70,15 @@ int64_t lcm_stats_bytes(int M, int N, int img_rows);
  * silently run with fewer parts, because that would change the numbers.  bytes >= 4*splits*M*N of the largest split
  * layer (64 MiB covers SD1.5 at batch 1, 384 MiB batch 8). */
 int lcm_set_workspace(void* ptr, int64_t bytes);
-/* a workspace of its own for the launches of one stream (ptr NULL: forget it): two sampler passes in flight on two
- * streams ("lanes") must not share split-K slabs.  Looked up before the device-wide workspace. */
+/* a workspace of its own for the launches of one stream: two sampler passes in flight on two streams ("lanes") must not share
+ * split-K slabs.  Looked up before the device-wide workspace.  An entry is OWNED by the pointer that registered it:
+ * (ptr, bytes > 0) registers -- LCM_EINVAL if the stream already carries another owner's workspace; (ptr, 0) forgets the entry
+ * only if it still holds ptr; (NULL, 0) forgets it whoever owns it. */
 int lcm_set_stream_workspace(void* stream, void* ptr, int64_t bytes);
+/* a hipStream_t of the caller's own (hipStreamNonBlocking).  Frameworks hand streams out of small recycled pools (torch: 32 per
+ * device), so two long-lived owners can end up keyed on one handle; a lane of the sampler takes its streams from here. */
+int lcm_stream_create(void** stream_out);
+int lcm_stream_destroy(void* stream);
 
 /* launch heuristics of the contraction kernels (0 keeps a value): workgroups a split-K launch aims for, the
  * maximum number of K splits, and the workgroup count below which a larger tile is passed over.  These feed the
@@ -167,7 +173,7 @@ int lcm_groupnorm_affine_f16(const void* x, int C1, const void* x2, int C2, cons
 /* launches of the LDS-halo conv with fewer workgroups than this use its pipelined variant (3-stage weight ring,
  * double-buffered halo) instead of the single-buffer high-occupancy one; default 768 */
 int lcm_set_halo_pipe_threshold(int wgs);
-/* GroupNorm-fused convolution (lcm_conv3x3_gn_f16 with scale / shift): 1 (default) = the raw halo of the next 64-channel chunk
+/* GroupNorm-fused convolution (lcm_conv3x3_gn_f16 with scale / shift): 1 = the raw halo of the next 64-channel chunk
  * is fetched into registers under the taps of the current one (measured slower: 202 VGPRs, two workgroups per CU instead of three), 0 (default) = fetched where it is consumed.  Bit-neutral. */
 int lcm_set_halo_prefetch(int on);
 /* 1 (default): stride-1 3x3 convolutions use the LDS-halo kernel; 0: the row-gather implicit GEMM everywhere */

@@ -76,60 +76,86 @@ class MicroBatcher:
         return key, batch
 
     def _loop(self, lane=0):
+        """A dispatcher thread never dies silently: whatever escapes one round (a bug in the gating, not a failed pass -- those
+        go to the waiters' futures) is reported and the thread goes on serving; a dead lane 0 would otherwise leave the other
+        lanes deferring to it forever."""
         while True:
-            with self._cv:
-                while not self._q and not self._closed:
-                    self._cv.wait()
-                if not self._q and self._closed:
-                    return
-                if lane > 0 and not self._lane0_busy and not self._closed:
-                    # lane 0 is idle and has been notified as well: the job is its to take.  A lone caller never touches
-                    # the other lanes (each owns ~1.3 GB of workspace, its own buffers, tune and graph capture on first use)
-                    self._cv.wait(0.05)
-                    continue
-                if lane > 0 and len(self._q) > self.lane_max_waiting and not self._closed:
-                    # high load: leave the queue to lane 0's next (larger) batch -- unless lane 0 is stuck inside one call
-                    # (multi-second first-use tune / graph capture, waiting for a style re-merge): then serve.  Woken by
-                    # lane 0's notify when it comes back for work, not by polling.
-                    stalled = self._lane0_busy and time.monotonic() - self._lane0_since > self.lane0_stall_s
-                    # ... or a FULL batch is already waiting behind lane 0's pass: two largest-size passes in flight finish
-                    # 9 % more images per second than one after the other (126.7 against 116.4 images/s at batch 8,
-                    # tools/lanes_sweep.py), and the waiting batch is done sooner than if it queued behind the running one
-                    head = self._q[0][0]
-                    full = sum(1 for e in self._q if e[0] == head) >= self.max_batch
-                    if not stalled and not full:
-                        self._cv.wait(self.lane0_stall_s)
-                        continue
-                if self.window > 0:
-                    head_key, deadline = self._q[0][0], self._q[0][3] + self.window
-                    while (sum(1 for e in self._q if e[0] == head_key) < self.max_batch and not self._closed):
-                        left = deadline - time.monotonic()
-                        if left <= 0:
-                            break
-                        self._cv.wait(left)
-                key, batch = self._take()
-                if lane == 0:
-                    self._lane0_busy, self._lane0_since = True, time.monotonic()
-                    if self._q and self.lanes > 1:
-                        self._cv.notify_all()         # what is left may now go to the other lanes
-            items = [e[1] for e in batch]
             try:
-                try:
-                    results = self.run_batch(key, items, lane) if self.lanes > 1 else self.run_batch(key, items)
-                finally:
-                    if lane == 0:
-                        with self._cv:
-                            self._lane0_busy = False
-                            self._cv.notify_all()     # the other lanes re-evaluate their gate
-                if len(results) != len(items):
-                    raise RuntimeError(f"run_batch returned {len(results)} results for {len(items)} items")
-                self.batches.append(len(items))
-                for e, r in zip(batch, results):
-                    e[2].set_result(r)
-            except BaseException as exc:            # every waiter of the failed pass sees the error (reference: the
-                for e in batch:                     # exception propagates out of run_job, backends/worker_pool.py:100-113)
-                    if not e[2].done():
-                        e[2].set_exception(exc)
+                if not self._round(lane):
+                    return
+            except BaseException as exc:            # noqa
+                import sys
+                import traceback
+                print(f"[lcm-microbatch] lane {lane}: dispatcher round failed: {exc!r}", file=sys.stderr)
+                traceback.print_exc()
+                if lane == 0:
+                    with self._cv:
+                        self._lane0_busy = False
+                        self._cv.notify_all()
+                time.sleep(0.01)
+
+    def _lane0_alive(self):
+        t = self._threads[0] if self._threads else None
+        return t is not None and t.is_alive()
+
+    def _round(self, lane):
+        """One pass of a dispatcher thread: wait for work, take a batch, run it.  -> False when the batcher is closed and empty."""
+        with self._cv:
+            while not self._q and not self._closed:
+                self._cv.wait()
+            if not self._q and self._closed:
+                return False
+            if lane > 0 and not self._lane0_busy and not self._closed and self._lane0_alive():
+                # lane 0 is idle and has been notified as well: the job is its to take.  A lone caller never touches
+                # the other lanes (each owns ~1.3 GB of workspace, its own buffers, tune and graph capture on first use)
+                self._cv.wait(0.05)
+                return True
+            if lane > 0 and len(self._q) > self.lane_max_waiting and not self._closed and self._lane0_alive():
+                # high load: leave the queue to lane 0's next (larger) batch -- unless lane 0 is stuck inside one call
+                # (multi-second first-use tune / graph capture, waiting for a style re-merge): then serve.  Woken by
+                # lane 0's notify when it comes back for work, not by polling.
+                stalled = self._lane0_busy and time.monotonic() - self._lane0_since > self.lane0_stall_s
+                # ... or a FULL batch is already waiting behind lane 0's pass: two largest-size passes in flight finish
+                # 9 % more images per second than one after the other (126.7 against 116.4 images/s at batch 8,
+                # tools/lanes_sweep.py), and the waiting batch is done sooner than if it queued behind the running one
+                head = self._q[0][0]
+                full = sum(1 for e in self._q if e[0] == head) >= self.max_batch
+                if not stalled and not full:
+                    self._cv.wait(self.lane0_stall_s)
+                    return True
+            if self.window > 0:
+                head_key, deadline = self._q[0][0], self._q[0][3] + self.window
+                while (self._q and sum(1 for e in self._q if e[0] == head_key) < self.max_batch and not self._closed):
+                    left = deadline - time.monotonic()
+                    if left <= 0:
+                        break
+                    self._cv.wait(left)
+                if not self._q:                     # the lock was released while waiting: another lane took the batch
+                    return True
+            key, batch = self._take()
+            if lane == 0:
+                self._lane0_busy, self._lane0_since = True, time.monotonic()
+                if self._q and self.lanes > 1:
+                    self._cv.notify_all()             # what is left may now go to the other lanes
+        items = [e[1] for e in batch]
+        try:
+            try:
+                results = self.run_batch(key, items, lane) if self.lanes > 1 else self.run_batch(key, items)
+            finally:
+                if lane == 0:
+                    with self._cv:
+                        self._lane0_busy = False
+                        self._cv.notify_all()         # the other lanes re-evaluate their gate
+            if len(results) != len(items):
+                raise RuntimeError(f"run_batch returned {len(results)} results for {len(items)} items")
+            self.batches.append(len(items))
+            for e, r in zip(batch, results):
+                e[2].set_result(r)
+        except BaseException as exc:                # every waiter of the failed pass sees the error (reference: the
+            for e in batch:                         # exception propagates out of run_job, backends/worker_pool.py:100-113)
+                if not e[2].done():
+                    e[2].set_exception(exc)
+        return True
 
     def close(self, timeout: float = 30.0):
         with self._cv:

@@ -49,12 +49,29 @@ _PNG_POOL_LOCK = threading.Lock()
 
 
 def _png_pool(n):
+    """Stripe-deflate threads.  The stripe COUNT of an image (and so its bytes) follows LCM_PNG_THREADS alone; the pool is
+    wider (up to the host's cores, at most 16) so that the images of a drained batch deflate side by side."""
     global _PNG_POOL
+    n = max(n, min(16, os.cpu_count() or 1))
     with _PNG_POOL_LOCK:
         if _PNG_POOL is None or _PNG_POOL._max_workers < n:
             from concurrent.futures import ThreadPoolExecutor
             _PNG_POOL = ThreadPoolExecutor(max_workers=n, thread_name_prefix="lcm-png")
         return _PNG_POOL
+
+
+_FINISH_POOL = None
+
+
+def _finish_pool():
+    """Threads that finish the jobs a ``run_job`` call drained from the pool's queue (PNG encode, set the job's future,
+    ``task_done``).  Separate from the stripe pool: a finisher blocks on its image's stripes."""
+    global _FINISH_POOL
+    with _PNG_POOL_LOCK:
+        if _FINISH_POOL is None:
+            from concurrent.futures import ThreadPoolExecutor
+            _FINISH_POOL = ThreadPoolExecutor(max_workers=min(16, max(4, os.cpu_count() or 4)), thread_name_prefix="lcm-finish")
+        return _FINISH_POOL
 
 
 def _deflate_stripe(args):
@@ -105,8 +122,11 @@ def encode_png(rgb) -> bytes:
 class _Engine:
     """Everything resident for one (family, device, checkpoint): the pipeline (weights, launch plans, captured graphs), the
     text encoders, the style adapters and the micro-batching dispatcher.  The reference builds one pipeline -- and one
-    weight copy -- per ``worker_id`` (backends/worker_pool.py:60-71); here the workers the pool creates for a GPU share one
-    engine, so N pool threads blocking in ``run_job`` become batched passes.  LCM_SHARE_ENGINE=0: one engine per worker.
+    weight copy -- per worker object (``DiffusersCudaWorker.__init__``, backends/cuda_worker.py:41-121; its ``WorkerPool`` creates
+    exactly one, ``worker_id=0``, backends/worker_pool.py:228; the legacy ``PipelineService`` one per ``NUM_WORKERS``,
+    forced to 1 on CUDA, server/lcm_sr_server.py:190-193).  Here the workers a caller creates for one GPU share one engine,
+    so N threads blocking in ``run_job`` become batched passes -- and behind the single-consumer ``WorkerPool`` the batch comes
+    from draining the pool's queue (``HipLcmWorker._drain``).  LCM_SHARE_ENGINE=0: one engine per worker.
 
     Lifetime: workers hold the engine, the engine never holds a worker, the registry and the dispatcher thread hold it
     weakly.  The pool's teardown -- ``del worker; gc.collect(); torch.cuda.empty_cache()`` (backends/worker_pool.py:270-276),
@@ -451,12 +471,9 @@ class HipLcmWorker:
     def _run_batch(self, key, items):
         return self._engine.run_batch(key, items)
 
-    def _submit(self, job):
+    def _prepare(self, req, key):
+        """-> (req, seed, noise): the seed policy of cuda_worker.py:210-213 and the request's RNG stream."""
         eng = self._engine
-        if eng is None or eng.pipe is None:
-            raise RuntimeError("worker is closed")
-        req = job.req
-        key = self._job_key(req)                     # raises the reference's size error in the caller's thread
         seed = int(req.seed) if getattr(req, "seed", None) is not None else int(torch.randint(0, 100_000_000, (1,)).item())
         # the request's RNG stream (initial latents, then one draw per remaining step) is drawn HERE, on the caller's
         # thread: pool threads do it in parallel and the GPU dispatcher's serial path shrinks by ~0.5 ms per request
@@ -464,14 +481,136 @@ class HipLcmWorker:
         noise = None
         if key[0] % 8 == 0 and key[1] % 8 == 0 and key[0] > 0 and key[1] > 0 and key[2] >= 1:
             noise = draw_noise(seed, key[1] // 8, key[0] // 8, key[2] - 1, eng.pipe.sched.init_noise_sigma)
+        return (req, seed, noise)
+
+    def _submit(self, job):
+        eng = self._engine
+        if eng is None or eng.pipe is None:
+            raise RuntimeError("worker is closed")
+        req = job.req
+        key = self._job_key(req)                     # raises the reference's size error in the caller's thread
+        item = self._prepare(req, key)
         b = eng.batcher
         if b is None:
-            return eng.run_batch(key, [(req, seed, noise)])[0], seed
-        return b.submit(key, (req, seed, noise)).result(), seed
+            return eng.run_batch(key, [item])[0], item[1]
+        return b.submit(key, item).result(), item[1]
+
+    # ---- batching behind the reference's single-consumer pool ------------------------------------------
+    def bind_queue(self, q) -> None:
+        """Tell the worker which ``queue.Queue`` its caller's consumer thread takes jobs from (``WorkerPool.q``,
+        backends/worker_pool.py:171).  Not needed behind ``get_worker_pool()``: that singleton is found by itself."""
+        self._pool_q = q
+
+    def _pool_queue(self):
+        q = getattr(self, "_pool_q", None)
+        if q is not None:
+            return q
+        if os.environ.get("LCM_DRAIN_QUEUE", "1").lower() in ("0", "false", "no", "off"):
+            return None
+        # the reference's process-wide pool (backends/worker_pool.py:421-469): looked up, never imported -- only when the
+        # reference's module is already loaded and its pool is the one currently holding THIS worker
+        import sys
+        mod = sys.modules.get("backends.worker_pool")
+        pool = getattr(mod, "_worker_pool", None) if mod is not None else None
+        if pool is not None and getattr(pool, "_worker", None) is self:
+            return getattr(pool, "q", None)
+        return None
+
+    def _drain(self, q, job, key, limit):
+        """Take from the pool's queue, under its own mutex, the queued jobs that can share this call's sampler pass.
+
+        ``WorkerPool._worker_loop`` is ONE thread that calls ``job.execute(worker)`` -> ``worker.run_job(job)`` and blocks
+        (backends/worker_pool.py:294-341, :84-88): ``run_job`` never sees a second job, so the batch has to be collected
+        here.  Rules: walk the queue from its head; a job qualifies when it is of the same class as the running one (the
+        pool would have called ``run_job`` for it too), carries ``.req`` and an unresolved ``.fut``, and its request agrees on
+        (size, steps, guidance, style); generation jobs with another key keep their place; the walk STOPS at the first
+        job of any other kind (a ``ModeSwitchJob`` / ``CustomJob`` is a barrier: nothing queued behind it is overtaken).
+        A drained job is finished here exactly as the loop would have (worker_pool.py:328-339): its future gets
+        ``(png, seed)`` or the exception, and ``q.task_done()`` is called for it."""
+        taken = []
+        if limit <= 0:
+            return taken
+        cls = type(job)
+        with q.mutex:
+            dq = q.queue
+            idx = []
+            for i, j in enumerate(dq):
+                if type(j) is not cls or not hasattr(j, "req") or getattr(j, "fut", None) is None:
+                    break                             # barrier
+                try:
+                    same = (not j.fut.done()) and self._job_key(j.req) == key
+                except Exception:
+                    same = False                      # malformed request: it raises from its own run_job call, in its turn
+                if same:
+                    idx.append(i)
+                    if len(idx) >= limit:
+                        break
+            for i in reversed(idx):
+                taken.append(dq[i])
+                del dq[i]
+            if idx:
+                q.not_full.notify(len(idx))           # space for blocked producers (Queue.put)
+        taken.reverse()
+        return taken
+
+    def _finish_drained(self, q, job, fut, seed):
+        """Runs on a finisher thread when the drained job's pass is done: what the pool's loop does for a job
+        (backends/worker_pool.py:328-339)."""
+        try:
+            rgb, _ = fut.result()
+            res = (encode_png(rgb), seed)
+            if not job.fut.done():
+                job.fut.set_result(res)
+        except BaseException as e:                    # noqa
+            try:
+                if not job.fut.done():
+                    job.fut.set_exception(e)
+            except Exception:
+                pass
+        finally:
+            q.task_done()
 
     def run_job(self, job) -> Tuple[bytes, int]:
-        (rgb, _), seed = self._submit(job)
-        return encode_png(rgb), seed
+        eng = self._engine
+        q = self._pool_queue() if eng is not None and getattr(eng, "batcher", None) is not None else None
+        if q is None or q.empty():
+            (rgb, _), seed = self._submit(job)
+            return encode_png(rgb), seed
+        if eng.pipe is None:
+            raise RuntimeError("worker is closed")
+        key = self._job_key(job.req)
+        b = eng.batcher
+        # as many as the lanes can have in flight as full batches (two batch-8 passes on two lanes: 127 against 116 images/s)
+        others = self._drain(q, job, key, b.max_batch * max(1, b.lanes) - 1)
+        if not others:
+            (rgb, _), seed = self._submit(job)
+            return encode_png(rgb), seed
+        pending, fin = [], _finish_pool()
+        try:
+            items = list(fin.map(lambda j: self._prepare(j.req, key), [job] + others))
+            futs = [b.submit(key, it) for it in items]
+        except BaseException as e:                    # noqa  nothing was started: the drained jobs fail like the running one
+            for j in others:
+                if not j.fut.done():
+                    j.fut.set_exception(e)
+                q.task_done()
+            raise
+        for j, f, it in zip(others, futs[1:], items[1:]):
+            done = threading.Event()
+            pending.append(done)
+
+            def _cb(f, j=j, seed=it[1], done=done):
+                done.set()                            # the GPU side of this job is over
+                fin.submit(self._finish_drained, q, j, f, seed)
+            f.add_done_callback(_cb)
+        try:
+            rgb, _ = futs[0].result()
+            return encode_png(rgb), items[0][1]
+        finally:
+            # return to the pool's loop only when every pass this call started has left the GPU (a mode switch may be next
+            # in the queue); the drained jobs' PNGs may still be deflating on the finisher threads -- no GPU state involved
+            for ev in pending:
+                ev.wait()
 
     def run_job_with_latents(self, job) -> Tuple[bytes, int, bytes]:
         # The reference re-runs the whole pipeline for the latents (cuda_worker.py:255-283); the sampler is

@@ -34,6 +34,24 @@ extern "C" int lcm_device_info(int dev, char* arch_buf, int buf_len, int* cu_cou
     return n;
 }
 
+// A stream that belongs to the caller alone (not one of a framework's pooled, recycled handles): a pipeline lane keys its
+// split-K workspace, its captured graphs and its launch order on it.
+extern "C" int lcm_stream_create(void** stream_out) {
+    if (!stream_out) { lcm_set_error("stream_create: null out pointer"); return LCM_EINVAL; }
+    hipStream_t s = nullptr;
+    hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    if (e != hipSuccess) { lcm_set_error("hipStreamCreateWithFlags: %s", hipGetErrorString(e)); return (int)e; }
+    *stream_out = (void*)s;
+    return LCM_OK;
+}
+
+extern "C" int lcm_stream_destroy(void* stream) {
+    if (!stream) return LCM_OK;
+    hipError_t e = hipStreamDestroy((hipStream_t)stream);
+    if (e != hipSuccess) { lcm_set_error("hipStreamDestroy: %s", hipGetErrorString(e)); return (int)e; }
+    return LCM_OK;
+}
+
 extern "C" int lcm_graph_begin(void* stream) {
     hipError_t e = hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal);
     if (e != hipSuccess) { lcm_set_error("hipStreamBeginCapture: %s", hipGetErrorString(e)); return (int)e; }

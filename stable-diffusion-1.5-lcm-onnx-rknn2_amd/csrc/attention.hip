@@ -234,9 +234,9 @@ template <int D, int WAVES>
 static int launch_attn_w(const AttnParams& p, hipStream_t s) {
     using C = AttnCfg<D>;
     static LcmDevOnce attr_once;
-    if (attr_once.first()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<D, WAVES>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+    if (auto once_guard = attr_once.first()) {
+        once_guard.check(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_kernel<D, WAVES>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
     }
     dim3 grid((p.Sq + 32 * WAVES - 1) / (32 * WAVES), p.B * p.heads);
     char nm[32];
@@ -639,8 +639,8 @@ static int launch_attn2_w(const AttnParams& p, hipStream_t s) {
     using C = Attn2Cfg<D>;
     static_assert(KS * C::LDS_BYTES <= 160 * 1024 && (KS == 1 || 4 * WAVES * (C::NDB * 16 + 2) * 64 <= KS * C::LDS_BYTES), "attn2 LDS");
     static LcmDevOnce attr_once;
-    if (attr_once.first()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn2_kernel<D, WAVES, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, KS * C::LDS_BYTES);
+    if (auto once_guard = attr_once.first()) {
+        once_guard.check(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn2_kernel<D, WAVES, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, KS * C::LDS_BYTES));
     }
     const int nqb = (p.Sq + 32 * WAVES - 1) / (32 * WAVES);
     char nm[40];
@@ -866,8 +866,8 @@ template <int D, int TK>
 static int launch_attn_wide(const AttnParams& p, hipStream_t s) {
     constexpr int LDS = 2 * 2 * TK * (D * 2 + 32);
     static LcmDevOnce attr_once;
-    if (attr_once.first()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_wide_kernel<D, TK>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (auto once_guard = attr_once.first()) {
+        once_guard.check(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_wide_kernel<D, TK>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     }
     dim3 grid((p.Sq + 63) / 64, p.B * p.heads);
     char nm[32];

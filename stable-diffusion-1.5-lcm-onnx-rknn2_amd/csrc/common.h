@@ -8,15 +8,37 @@ typedef _Float16 half_t;
 // hipFuncSetAttribute (the dynamic-LDS limit of a kernel) holds for the CURRENT device only: a process that drives several
 // GPUs (LCM_DEVICES=all: worker i on cuda:i) must set it once per device, not once per process.
 #include <atomic>
+#include <mutex>
+// `if (auto g = once.first()) { g.check(hipFuncSetAttribute(...)); }`: the guard holds the mutex while the caller raises the
+// limit, and the device is marked done only when the guard goes out of scope with every call having succeeded -- a second
+// thread making its first launch on the same device waits for the attribute instead of launching ahead of it.
 struct LcmDevOnce {
-    std::atomic<unsigned long long> mask{0};
-    bool first() {
+    std::atomic<unsigned long long> done{0};
+    std::mutex mu;
+    struct Guard {
+        LcmDevOnce* o;
+        unsigned long long bit;
+        hipError_t err;
+        Guard(LcmDevOnce* o_, unsigned long long b) : o(o_), bit(b), err(hipSuccess) {}
+        Guard(const Guard&) = delete;
+        Guard(Guard&& g) : o(g.o), bit(g.bit), err(g.err) { g.o = nullptr; }
+        explicit operator bool() const { return o != nullptr; }
+        void check(hipError_t e) { if (e != hipSuccess && err == hipSuccess) err = e; }
+        ~Guard() {
+            if (!o) return;
+            if (err == hipSuccess) o->done.fetch_or(bit, std::memory_order_release);
+            else fprintf(stderr, "[lcm] hipFuncSetAttribute failed: %s\n", hipGetErrorString(err));
+            o->mu.unlock();
+        }
+    };
+    Guard first() {
         int d = 0;
         (void)hipGetDevice(&d);
         const unsigned long long bit = 1ull << (d & 63);
-        if (mask.load(std::memory_order_relaxed) & bit) return false;
-        mask.fetch_or(bit, std::memory_order_relaxed);
-        return true;
+        if (done.load(std::memory_order_acquire) & bit) return Guard(nullptr, 0);
+        mu.lock();
+        if (done.load(std::memory_order_relaxed) & bit) { mu.unlock(); return Guard(nullptr, 0); }
+        return Guard(this, bit);
     }
 };
 

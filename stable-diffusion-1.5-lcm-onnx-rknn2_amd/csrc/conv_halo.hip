@@ -501,9 +501,9 @@ static void launch_halo(HaloParams& hp, hipStream_t s, int force) {     // force
         constexpr int smem = 2 * HROWS_PAD * 128 + WS * TPS * BN * 128;
         static_assert(smem <= 160 * 1024, "halo ring exceeds LDS");
         static LcmDevOnce attr_once;
-        if (attr_once.first()) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_pipe_kernel<TH, TW, BN, WS, PH, TPS, 1>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (auto once_guard = attr_once.first()) {
+            once_guard.check(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_pipe_kernel<TH, TW, BN, WS, PH, TPS, 1>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         }
         char nm[80];
         snprintf(nm, sizeof(nm), "conv_halo_pipe_kernel<%d, %d, %d, %d, %d, %d, 1>", TH, TW, BN, WS, PH, TPS);
@@ -519,9 +519,9 @@ static void launch_halo(HaloParams& hp, hipStream_t s, int force) {     // force
         constexpr int smem = 2 * HROWS_PAD * 128 + WS * TPS * BN * 128;
         static_assert(smem <= 160 * 1024, "row-step halo ring exceeds LDS");
         static LcmDevOnce attr_once;
-        if (attr_once.first()) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_pipe_kernel<TH, TW, BN, WS, PH, TPS>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (auto once_guard = attr_once.first()) {
+            once_guard.check(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_pipe_kernel<TH, TW, BN, WS, PH, TPS>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         }
         char nm[64];
         snprintf(nm, sizeof(nm), "conv_halo_pipe_kernel<%d, %d, %d, %d, %d, %d>%s", TH, TW, BN, WS, PH, TPS, hp.g.splits > 1 ? " +splitk" : "");
@@ -534,9 +534,9 @@ static void launch_halo(HaloParams& hp, hipStream_t s, int force) {     // force
         constexpr int WS = 3;
         constexpr int smem = 2 * HROWS_PAD * 128 + WS * BN * 128;
         static LcmDevOnce attr_once;
-        if (attr_once.first()) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_pipe_kernel<TH, TW, BN, WS, PH, 1>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (auto once_guard = attr_once.first()) {
+            once_guard.check(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_pipe_kernel<TH, TW, BN, WS, PH, 1>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         }
         char nm[64];
         snprintf(nm, sizeof(nm), "conv_halo_pipe_kernel<%d, %d, %d, %d, %d, 1>%s", TH, TW, BN, WS, PH, hp.g.splits > 1 ? " +splitk" : "");

@@ -515,10 +515,23 @@ extern "C" int lcm_set_workspace(void* ptr, int64_t bytes) {
     return LCM_OK;
 }
 
+// Ownership: an entry belongs to whoever registered it, identified by the workspace pointer.  Registering another pointer over
+// a live entry is refused (two owners on one stream handle would silently share -- or free -- each other's slabs: torch hands
+// its streams out of a 32-entry pool per device, so handles repeat); (ptr, bytes == 0) forgets the entry only if it still holds
+// that pointer; (NULL, 0) forgets it unconditionally.
 extern "C" int lcm_set_stream_workspace(void* stream, void* ptr, int64_t bytes) {
     std::lock_guard<std::mutex> lk(g_ws_mu);
-    if (ptr) g_stream_ws[(hipStream_t)stream] = StreamWs{(float*)ptr, (long long)bytes};
-    else g_stream_ws.erase((hipStream_t)stream);
+    auto it = g_stream_ws.find((hipStream_t)stream);
+    if (ptr && bytes > 0) {
+        if (it != g_stream_ws.end() && it->second.ptr != (float*)ptr) {
+            lcm_set_error("set_stream_workspace: stream %p already carries the workspace %p of another owner (new %p): "
+                          "every lane needs a stream of its own", stream, (void*)it->second.ptr, ptr);
+            return LCM_EINVAL;
+        }
+        g_stream_ws[(hipStream_t)stream] = StreamWs{(float*)ptr, (long long)bytes};
+    } else if (it != g_stream_ws.end() && (!ptr || it->second.ptr == (float*)ptr)) {
+        g_stream_ws.erase(it);
+    }
     return LCM_OK;
 }
 
@@ -699,9 +712,9 @@ template <int BM, int BN, int MODE, int S, int LN = 0, int SEG = 0>
 static int launch_v2(IgemmParams& p, dim3 grid, hipStream_t s) {
     constexpr int smem = S * (BM + BN) * 128 + (LN ? 2 * BN * 4 : 0);       // LN: + this n-tile's ln_g | ln_c
     static LcmDevOnce attr_once;
-    if (attr_once.first()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<BM, BN, MODE, S, LN, SEG>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (auto once_guard = attr_once.first()) {
+        once_guard.check(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<BM, BN, MODE, S, LN, SEG>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     }
     char nm[64];
     snprintf(nm, sizeof(nm), "igemm2_kernel<%d, %d, %d, %d, %d, %d>%s", BM, BN, MODE, S, LN, SEG, p.splits > 1 ? " +splitk" : "");
@@ -753,9 +766,9 @@ static int launch_cfg(IgemmParams& p, int batch, int splits, int plan_variant, h
     if (variant == 0) {
         const int smem = 2 * (BM + BN) * 128;
         static LcmDevOnce attr_once;
-        if (attr_once.first()) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, MODE, LN>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (auto once_guard = attr_once.first()) {
+            once_guard.check(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<BM, BN, MODE, LN>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         }
         char nm[64];
         snprintf(nm, sizeof(nm), "igemm_kernel<%d, %d, %d, %d>%s", BM, BN, MODE, LN, p.splits > 1 ? " +splitk" : "");

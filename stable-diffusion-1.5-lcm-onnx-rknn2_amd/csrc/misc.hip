@@ -110,8 +110,8 @@ extern "C" int lcm_conv3x3_c4_f32in(const void* in, const void* pre_w, const voi
     LCM_REQUIRE((pre_w == nullptr) == (pre_b == nullptr), "conv_c4: pre_w/pre_b must come together");
     const int smem = Cout * 192;
     static LcmDevOnce attr_once;
-    if (attr_once.first()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_c4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (auto once_guard = attr_once.first()) {
+        once_guard.check(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_c4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     const long long ntile = ((long long)B * H * Wd + 15) / 16;
     // persistent: the weights are staged once per workgroup; at most two workgroups per CU
@@ -402,11 +402,11 @@ static int launch_conv_fewout(const void* in, const void* gn_scale, const void* 
     const int smem = (tw == 16 ? 184 : 104) * 128 + 36 * Cin * 2;
     LCM_REQUIRE(smem <= 160 * 1024, "conv_smalln: weights %d bytes exceed LDS", 36 * Cin * 2);
     static LcmDevOnce attr_once;
-    if (attr_once.first()) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fewout_kernel<0, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fewout_kernel<1, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fewout_kernel<0, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fewout_kernel<1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (auto once_guard = attr_once.first()) {
+        once_guard.check(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fewout_kernel<0, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        once_guard.check(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fewout_kernel<1, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        once_guard.check(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fewout_kernel<0, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        once_guard.check(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_fewout_kernel<1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     }
     const long long ntile = (long long)B * ((H + 7) / 8) * ((Wd + tw - 1) / tw);
     const int per_cu = 160 * 1024 / smem < 4 ? 160 * 1024 / smem : 4;

@@ -52,6 +52,8 @@ _SIGS = {
     "lcm_timestep_embedding_steps": [_vp, _i, _vp, _i, _i, _vp],
     "lcm_scheduler_step": [_vp, _vp, _f, _vp, _vp, C.POINTER(C.c_float), _i, _i, _i, _i, _vp],
     "lcm_latents_pool8": [_vp, _vp, _i, _i, _i, _vp],
+    "lcm_stream_create": [C.POINTER(_vp)],
+    "lcm_stream_destroy": [_vp],
     "lcm_graph_begin": [_vp],
     "lcm_graph_end": [_vp, C.POINTER(_vp)],
     "lcm_graph_launch": [_vp, _vp],

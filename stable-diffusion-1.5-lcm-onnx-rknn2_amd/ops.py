@@ -417,11 +417,40 @@ def set_workspace(t):
     _lib.check(L.lcm_set_workspace(_p(t), 0 if t is None else t.numel() * t.element_size()), "lcm_set_workspace")
 
 
-def set_stream_workspace(stream, t):
-    """A split-K workspace of its own for the launches of ``stream`` (a torch.cuda.Stream); None forgets it."""
+def set_stream_workspace(stream, t, forget=False):
+    """A split-K workspace of its own for the launches of ``stream`` (a torch.cuda.Stream).  The entry is owned by the tensor
+    that registered it: registering another tensor over a live entry raises; ``forget=True`` removes the entry only if it still
+    holds ``t``; ``t=None`` removes it whoever owns it."""
     L = _lib.load()
-    _lib.check(L.lcm_set_stream_workspace(C.c_void_p(stream.cuda_stream), _p(t), 0 if t is None else t.numel() * t.element_size()),
-               "lcm_set_stream_workspace")
+    nbytes = 0 if (t is None or forget) else t.numel() * t.element_size()
+    _lib.check(L.lcm_set_stream_workspace(C.c_void_p(stream.cuda_stream), _p(t), nbytes), "lcm_set_stream_workspace")
+
+
+_OWN_STREAMS = {}            # device index -> idle streams created through lcm_stream_create
+
+
+def acquire_stream(device):
+    """A stream no other owner in this process holds: torch.cuda.Stream() hands handles out of a 32-entry round-robin pool per
+    device, so after ~16 lanes (engine reloads, an SD1.5 beside an SDXL engine, a long test session) two live pipelines would
+    be keyed on ONE handle -- and the library keys a lane's split-K workspace on it.  Streams come from lcm_stream_create,
+    wrapped as torch.cuda.ExternalStream, and go back to an idle list on release (never destroyed: the allocator may still
+    hold blocks tagged with them)."""
+    import torch
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    idle = _OWN_STREAMS.setdefault(idx, [])
+    if idle:
+        return idle.pop()
+    L = _lib.load()
+    out = C.c_void_p()
+    with torch.cuda.device(idx):
+        _lib.check(L.lcm_stream_create(C.byref(out)), "lcm_stream_create")
+    return torch.cuda.ExternalStream(out.value, device=torch.device("cuda", idx))
+
+
+def release_stream(stream):
+    if stream is not None:
+        _OWN_STREAMS.setdefault(stream.device.index, []).append(stream)
 
 
 def set_tuning(target_wgs=0, max_splits=0, min_wgs=0):

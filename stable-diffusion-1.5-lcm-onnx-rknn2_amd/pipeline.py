@@ -87,7 +87,7 @@ class _Lane:
     def __init__(self, pipe, index, unet, vae):
         self.index = index
         self.unet, self.vae = unet, vae
-        self.stream = torch.cuda.Stream(device=pipe.device)
+        self.stream = ops.acquire_stream(pipe.device)       # a handle of this lane's own (not torch's recycled pool)
         self.plans = {}
         # The split-K workspace belongs to THIS lane of THIS pipeline (the library looks it up by launch stream): two
         # pipelines on one GPU -- an SD1.5 and an SDXL engine, or unshared engines of several pool workers -- run on threads
@@ -97,7 +97,7 @@ class _Lane:
         ops.set_stream_workspace(self.stream, self.splitk_ws)
         # side stream: launches that fork off the main chain inside one pass (the resnets' conv_shortcut GEMMs), with a
         # split-K workspace of its own -- they run concurrently with the main stream's split layers
-        self.side = torch.cuda.Stream(device=pipe.device)
+        self.side = ops.acquire_stream(pipe.device)
         self.side_ws = _new_workspace(pipe.device, mb=256)
         ops.set_stream_workspace(self.side, self.side_ws)
         self.unet.side_stream = self.side
@@ -269,8 +269,11 @@ class LcmHipPipeline:
             L.plans.clear()
             try:
                 torch.cuda.synchronize(self.device)
-                ops.set_stream_workspace(L.stream, None)
-                ops.set_stream_workspace(L.side, None)
+                ops.set_stream_workspace(L.stream, L.splitk_ws, forget=True)      # only if the entry is still this lane's
+                ops.set_stream_workspace(L.side, L.side_ws, forget=True)
+                ops.release_stream(L.stream)
+                ops.release_stream(L.side)
+                L.stream = L.side = None
             except Exception:
                 pass
 

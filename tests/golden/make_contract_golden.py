@@ -10,6 +10,9 @@ same way, tests/test_worker_pool.py:14-17) this drives
                                          the seed policy and the error text for malformed sizes
   RKNN2LatentConsistencyPipeline.check_inputs   backends/rknnlcm.py:370-415   accept / reject cases with the messages
   rknn_worker._latent_to_nchw            backends/rknn_worker.py:182-220   layouts in -> NCHW out, and the error cases
+  WorkerPool                             backends/worker_pool.py:135-419   the scripted session of tests/pool_scenario.py with a
+                                         recording fake factory / worker: factory keywords, thread names, environment, futures,
+                                         exception path, same-mode switch no-op, teardown order, queue-full error
 
 Output: tests/golden/worker_contract.json (+ the arrays in tests/golden/worker_contract.npz).  Data only: inputs, recorded calls,
 outputs, messages -- no reference source text.
@@ -159,13 +162,57 @@ def record_latent_to_nchw(rknn_worker):
     return recs, errs, arrays
 
 
+def record_pool():
+    """The reference's WorkerPool (backends/worker_pool.py:135-419) driven by tests/pool_scenario.py with a recording fake
+    worker, plain stand-ins for its ModeConfigManager / ModelRegistry collaborators (dependency injection, :147-181)."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from pool_scenario import run_scenario
+    import backends.worker_pool as wp
+    wp.reset_worker_pool()
+
+    class Mode:
+        def __init__(self, name, model):
+            self.name, self.model, self.model_path, self.loras = name, model, "/models/" + model, []
+
+    class ModeConfig:
+        class config:
+            model_root = "/models"
+        modes = {"mode-a": Mode("mode-a", "a.safetensors"), "mode-b": Mode("mode-b", "b.safetensors")}
+
+        def get_mode(self, name):
+            return self.modes[name]
+
+        def get_default_mode(self):
+            return "mode-a"
+
+    def make_pool(factory, registry_event, queue_max):
+        class Registry:
+            def get_used_vram(self):
+                return 0
+
+            def register_model(self, name, **kw):
+                registry_event("register", name)
+
+            def unregister_model(self, name):
+                registry_event("unregister", name)
+
+        return wp.WorkerPool(queue_max=queue_max, worker_factory=factory, mode_config=ModeConfig(), registry=Registry())
+
+    import logging
+    logging.disable(logging.CRITICAL)
+    try:
+        return run_scenario(make_pool, wp.GenerationJob, wp.ModeSwitchJob, wp.CustomJob)
+    finally:
+        logging.disable(logging.NOTSET)
+
+
 def main():
     rknnlcm, rknn_worker = import_reference()
     run_job, seed_policy = record_run_job()
     l2n, l2n_err, arrays = record_latent_to_nchw(rknn_worker)
     doc = dict(source="recorded from /root/reference under sys.modules stubs (tests/golden/make_contract_golden.py)",
                run_job=run_job, seed_policy_without_seed=seed_policy, check_inputs=record_check_inputs(rknnlcm),
-               latent_to_nchw=l2n, latent_to_nchw_errors=l2n_err)
+               latent_to_nchw=l2n, latent_to_nchw_errors=l2n_err, pool=record_pool())
     with open(os.path.join(HERE, "worker_contract.json"), "w") as f:
         json.dump(doc, f, indent=1, sort_keys=True, default=str)
     np.savez_compressed(os.path.join(HERE, "worker_contract.npz"), **arrays)

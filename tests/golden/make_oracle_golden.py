@@ -5,8 +5,9 @@ small fixtures, so the GPU suite does not spend minutes of CPU oracle time on ev
   python tests/golden/make_oracle_golden.py [case ...]      -> tests/golden/oracle_<case>.npz
 
 What is stored per case: the inputs' seeds (the tests rebuild the identical fp16 embeddings / noise from them), the oracle's
-final latents in full (fp32) and the decoded image on a stride-4 pixel grid (fp16, [-1, 1] pre-clamp values clipped to +-4;
-1/16 of the pixels, every row / column phase visited once across the channels' offsets), plus the same grid of the u8 image.
+final latents in full (fp32), the oracle's u8 image IN FULL (``u8_full`` [H, W, 3]: every pixel is checked -- a u8 value pins the
+oracle's [0, 1] float to +-0.5/255, which the test subtracts from the 1e-2 tolerance), and the decoded float image on a stride-4
+pixel grid (fp16, [-1, 1] pre-clamp values clipped to +-4) for an exact float comparison on 1/16 of the pixels.
 The oracle is this repo's CPU restatement (oracle/, parity unpinned at the diffusers boundary: oracle/__init__.py); the
 weights are the seeded synthetic ones both sides generate.  Small sizes keep a live oracle run in the tests.
 """
@@ -37,7 +38,7 @@ def save(case, ref, **meta):
     u8 = ref["image_u8"]                       # [1, H, W, 3]
     np.savez_compressed(os.path.join(HERE, f"oracle_{case}.npz"),
                         latents=ref["latents"].astype(np.float32), image_grid=grid(img).astype(np.float16),
-                        u8_grid=u8[0][::STRIDE, ::STRIDE].copy(), stride=np.int32(STRIDE),
+                        u8_grid=u8[0][::STRIDE, ::STRIDE].copy(), u8_full=u8[0].copy(), stride=np.int32(STRIDE),
                         **{k: np.asarray(v) for k, v in meta.items()})
     print(f"[golden] {case}: latents {ref['latents'].shape}, grid {grid(img).shape}, "
           f"{os.path.getsize(os.path.join(HERE, f'oracle_{case}.npz')) / 1e3:.0f} KB", flush=True)

@@ -641,3 +641,23 @@ def test_bench_traffic_lookup_reads_committed_pmc_table(tmp_path, capsys):
     bench.TRAFFIC_FILE = str(tmp_path / "missing.json")
     t, src = bench._pmc_traffic("void k<1>(P)", 1)
     assert t is None and "unreadable" in src
+
+
+def test_stream_workspace_entries_are_owned_by_their_pointer():
+    """workspaces are keyed by launch stream, and framework streams are recycled handles -- a second owner on one handle
+    must be refused, and one owner's unregister must not erase another's entry.  Pure host bookkeeping: no GPU involved."""
+    import ctypes as C
+    from sdlcm_amd import lib
+    L = lib.load()
+    s1, a, b = C.c_void_p(0x1000), C.c_void_p(0xA000), C.c_void_p(0xB000)
+    assert L.lcm_set_stream_workspace(s1, a, 1 << 20) == 0
+    assert L.lcm_set_stream_workspace(s1, a, 2 << 20) == 0                 # the owner may re-register (grow)
+    assert L.lcm_set_stream_workspace(s1, b, 1 << 20) != 0                 # another owner on the same handle: refused
+    assert b"another owner" in L.lcm_last_error()
+    assert L.lcm_set_stream_workspace(s1, b, 0) == 0                       # b forgetting "its" entry leaves a's alone ...
+    assert L.lcm_set_stream_workspace(s1, b, 1 << 20) != 0                 # ... (still a's)
+    assert L.lcm_set_stream_workspace(s1, a, 0) == 0                       # a forgets its own
+    assert L.lcm_set_stream_workspace(s1, b, 1 << 20) == 0                 # now the handle is free
+    assert L.lcm_set_stream_workspace(s1, None, 0) == 0                    # unconditional
+    assert L.lcm_set_stream_workspace(s1, a, 1 << 20) == 0
+    assert L.lcm_set_stream_workspace(s1, None, 0) == 0

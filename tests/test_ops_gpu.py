@@ -1157,3 +1157,39 @@ def test_statistics_buffer_exact_size_and_guard(H, W, Cin, Cout):
             ops.conv3x3(x, w, out, 1, H, W, Cin, Cout, stats=small)
     finally:
         ops.set_workspace(None)
+
+
+@pytest.mark.gpu
+def test_lane_streams_are_never_recycled_handles():
+    """torch.cuda.Stream() hands out 32 pooled handles per device round-robin, so long-lived owners collide after ~16
+    lanes.  Lanes take streams from lcm_stream_create instead: distinct while held, reused only after release; and the library
+    refuses a second workspace owner on a live handle."""
+    import torch
+    from sdlcm_amd import ops
+    from sdlcm_amd.lib import LcmHipError
+    held = [ops.acquire_stream("cuda:0") for _ in range(40)]
+    assert len({s.cuda_stream for s in held}) == 40
+    pooled = {torch.cuda.Stream(device="cuda:0").cuda_stream for _ in range(64)}
+    assert len(pooled) <= 32 and not (pooled & {s.cuda_stream for s in held})
+    a, b = torch.empty(1 << 18, device="cuda:0"), torch.empty(1 << 18, device="cuda:0")
+    ops.set_stream_workspace(held[0], a)
+    with pytest.raises(LcmHipError, match="another owner"):
+        ops.set_stream_workspace(held[0], b)
+    ops.set_stream_workspace(held[0], b, forget=True)           # not b's entry: stays
+    with pytest.raises(LcmHipError, match="another owner"):
+        ops.set_stream_workspace(held[0], b)
+    ops.set_stream_workspace(held[0], a, forget=True)
+    ops.set_stream_workspace(held[0], b)
+    ops.set_stream_workspace(held[0], b, forget=True)
+    # work runs on such a stream like on any other
+    with torch.cuda.stream(held[1]):
+        x = torch.ones(1024, device="cuda:0") * 3
+    held[1].synchronize()
+    assert float(x.sum()) == 3072.0
+    handles = {s.cuda_stream for s in held}
+    for s in held:
+        ops.release_stream(s)
+    again = [ops.acquire_stream("cuda:0") for _ in range(40)]
+    assert {s.cuda_stream for s in again} == handles
+    for s in again:
+        ops.release_stream(s)

@@ -140,6 +140,38 @@ def test_concurrent_callers_share_engine_and_coalesce(worker):
     assert np.abs(dec(png) - solo[0]).max() == 0
 
 
+def test_single_consumer_pool_drains_queue_into_one_pass(worker):
+    """SURVEY f4 behind the reference's actual caller: ``WorkerPool`` has ONE consumer thread (backends/worker_pool.py:294-341),
+    so the batch comes from ``run_job`` draining the compatible jobs queued behind the running one.  Eight queued requests ->
+    one batch-8 pass; every future gets the PNG bytes of ITS solo run; a mode-switch job in the queue is not overtaken."""
+    import sys, threading
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from tools import minipool
+    solo = {s: worker.run_job(MockJob(MockGenerateRequest(prompt=f"prompt {s}", size="256x256", seed=s))) for s in range(10)}
+    pool = minipool.MiniPool(lambda worker_id: worker, {"m": "synthetic"}, "m")
+    worker.bind_queue(pool.q)
+    try:
+        gate, inside = threading.Event(), threading.Event()
+        hold = pool.submit_job(minipool.CustomJob(handler=lambda: (inside.set(), gate.wait(30))))
+        assert inside.wait(30)
+        n0 = len(worker._engine.batcher.batches)
+        futs = [pool.submit_job(minipool.GenerationJob(req=MockGenerateRequest(prompt=f"prompt {s}", size="256x256", seed=s))) for s in range(8)]
+        sw = pool.submit_job(minipool.ModeSwitchJob(target_mode="m"))
+        tail = [pool.submit_job(minipool.GenerationJob(req=MockGenerateRequest(prompt=f"prompt {s}", size="256x256", seed=s))) for s in (8, 9)]
+        gate.set()
+        hold.result(60)
+        res = [f.result(600) for f in futs]
+        assert sw.result(60)["status"] == "already_loaded"
+        res += [f.result(600) for f in tail]
+        pool.q.join()
+        assert res == [solo[s] for s in range(10)]                                   # (png bytes, seed), byte for byte
+        assert worker._engine.batcher.batches[n0:] == [8, 2]                       # one pass of 8; the two behind the switch after it
+    finally:
+        worker.bind_queue(None)
+        pool._worker = None                                                          # the module's fixture owns the worker
+        pool.shutdown()
+
+
 def test_sdxl_worker_contract():
     """DiffusersSDXLCudaWorker's behavioural contract (tests/test_sdxl_worker.py in the reference) on the SDXL-family HIP
     worker with synthetic full-size SDXL weights: (bytes,int), PNG, seed echo, determinism, 512-byte latents, CFG path."""
