@@ -120,6 +120,17 @@ int lcm_canonical_splits(int kind, int m_img, int N, int K, int aux, int ph);
  * epilogue: LCM_EPI_NONE or LCM_EPI_GEGLU (ln_g / ln_c in the packed row order of W).  img_rows as lcm_gemm_f16. */
 int lcm_gemm_ln_f16(const void* A, int lda, const void* W, const void* ln_g, const void* ln_c, float eps,
                     void* out, int ldo, int M, int N, int K, int epilogue, int img_rows, void* stream);
+
+/* FeedForward of a BasicTransformerBlock in ONE launch:  out = x + Linear_2( GEGLU( Linear_1( LayerNorm(x) ) ) )
+ * = lcm_gemm_ln_f16(epilogue GEGLU) followed by lcm_gemm_f16(bias b2, residual x), bit for bit, with the [M, 4C] intermediate
+ * kept in registers (replaces diffusers' FeedForward(activation_fn="geglu") under norm3 and the residual add).
+ * W1 [8C][C]: gamma (*) W of ff.net.0.proj, value / gate rows interleaved in blocks of 16; ln_g / ln_c [8C] fp32 as for
+ * lcm_gemm_ln_f16; W2 [C][4C]: ff.net.2 with its columns in the stored order of the GEGLU output ("operand order": channel
+ * 16 P + 4 q + j at column 32 (P >> 1) + 8 q + 4 (P & 1) + j -- the order in which lcm_gemm_*_f16's GEGLU epilogue stores it).
+ * out may alias x (every workgroup reads and writes only its own 128 rows).  C = 320 only; a layer whose canonical K
+ * partition of the second product has parts (img_rows small) is refused with LCM_EINVAL: use the two launches. */
+int lcm_mlp_geglu_f16(const void* x, int ldx, const void* W1, const void* ln_g, const void* ln_c, float eps,
+                      const void* W2, const void* b2, void* out, int ldo, int M, int C, int img_rows, void* stream);
 /* refresh ln_g (= row sums of the live fp16 W') and ln_c (= c_base + alpha * c_delta; c_out / c_delta may be NULL) after
  * a style LoRA re-merged W' in place */
 int lcm_ln_fold_refresh(const void* W, int N, int K, const void* c_base, const void* c_delta, float alpha,

@@ -85,6 +85,27 @@ __device__ __forceinline__ void ln_finish(float (&s)[TM], float (&q)[TM], int K,
     }
 }
 
+// One lane's value / gate quad of the LayerNorm-folded GEGLU projection -> x * gelu(gate) in fp16.  THE element math of that
+// epilogue: the GEMM epilogue below and the fused FeedForward kernel (mlp_fused.hip) both call it, so they round alike.
+__device__ __forceinline__ h4 geglu_ln_quad(f4 x, f4 g, float ln_r, float ln_mu, const f4& gx, const f4& cx, const f4& gg, const f4& cg) {
+#pragma clang fp contract(off)
+    h4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float xv = __builtin_fmaf(ln_r, __builtin_fmaf(-ln_mu, gx[j], x[j]), cx[j]);
+        const float gv = __builtin_fmaf(ln_r, __builtin_fmaf(-ln_mu, gg[j], g[j]), cg[j]);
+        o[j] = (half_t)(xv * gelu_erf_f(gv));
+    }
+    return o;
+}
+
+// Column of the GEGLU output [M][F] that holds value channel 16 P + 4 fq + j: "operand order".  Within every group of 32 the
+// columns are arranged so that 8 consecutive ones are exactly what ONE lane of the producing MFMA tiles holds (the quads of
+// value/gate pair 2u and of pair 2u+1): the consumer (ff.net.2, its weight columns packed alike: packing.pack_ff2_cols) then
+// multiplies the same values in the same k slots whether it reads them back from memory or takes them from the producer's
+// registers (mlp_fused.hip).
+__device__ __forceinline__ int geglu_store_col(int P, int fq) { return 32 * (P >> 1) + 8 * fq + 4 * (P & 1); }
+
 template <int BM, int BN>
 __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f4 (&acc)[BN / 32][BM / 32], const int (&m_of)[BM / 32],
                                                int n_wave, int fq, int z, const int (&slab_of)[BM / 64],
@@ -190,7 +211,7 @@ row16_sum8(ssum, ssq);
                 bx = (f4){(float)tx[0], (float)tx[1], (float)tx[2], (float)tx[3]};
                 bg = (f4){(float)tg[0], (float)tg[1], (float)tg[2], (float)tg[3]};
             }
-            const int nout = ((n_wave + a * 16) >> 1) + fq * 4;
+            const int nout = geglu_store_col((n_wave + a * 16) >> 5, fq);      // operand order (see geglu_store_col)
             f4 gx = {0.f, 0.f, 0.f, 0.f}, cx = gx, gg = gx, cg = gx;
             if (ln_mu) {
                 if (ln_lds) {
@@ -208,19 +229,11 @@ row16_sum8(ssum, ssq);
             for (int b = 0; b < TM; ++b) {
                 const int m = m_of[b];
                 if (m < 0) continue;
-                f4 x = acc[a][b], g = acc[a + 1][b];
-                if (ln_mu) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        x[j] = __builtin_fmaf(ln_r[b], __builtin_fmaf(-ln_mu[b], gx[j], x[j]), cx[j]);
-                        g[j] = __builtin_fmaf(ln_r[b], __builtin_fmaf(-ln_mu[b], gg[j], g[j]), cg[j]);
-                    }
-                }
                 h4 o;
                 if (ln_mu) {          // the folded LayerNorm's constants already carry the bias (lcm_gemm_ln_f16 takes none)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = (half_t)(x[j] * gelu_erf_f(g[j]));
+                    o = geglu_ln_quad(acc[a][b], acc[a + 1][b], ln_r[b], ln_mu[b], gx, cx, gg, cg);
                 } else {
+                    const f4 x = acc[a][b], g = acc[a + 1][b];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) o[j] = (half_t)((x[j] + bx[j]) * gelu_erf_f(g[j] + bg[j]));
                 }

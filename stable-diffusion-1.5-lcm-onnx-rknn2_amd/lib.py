@@ -34,6 +34,7 @@ _SIGS = {
     "lcm_gemm_f16": [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _i,
                      _i64, _i64, _i64, _i, _vp, _i64, C.POINTER(_i), _vp],
     "lcm_gemm_ln_f16": [_vp, _i, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "lcm_mlp_geglu_f16": [_vp, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "lcm_ln_fold_refresh": [_vp, _i, _i, _vp, _vp, _f, _vp, _vp, _vp],
     "lcm_conv3x3_f16": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i64, C.POINTER(_i), _vp],
     "lcm_groupnorm_from_stats_f16": [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp, _vp],

@@ -22,7 +22,7 @@ import re
 import torch
 
 from . import ops
-from .packing import pack_conv1x1, pack_conv3x3, pack_conv3x3_up2, pack_geglu
+from .packing import pack_conv1x1, pack_conv3x3, pack_conv3x3_up2, pack_ff2_cols, pack_geglu
 from .weights import unet_param_spec
 
 
@@ -134,7 +134,7 @@ class LoraStyle:
                 dp, dcp = pack_geglu(dg, dc)
                 acc(q + ".ff1.w", (0, dp.shape[0]), dp, dcp)
             elif sub == "ff.net.2":
-                acc(q + ".ff2.w", (0, C), d)
+                acc(q + ".ff2.w", (0, C), pack_ff2_cols(d))          # columns in the GEGLU output's stored order
         dev = unet.device
         self.delta = {n: t.to(torch.float16).to(dev).contiguous() for n, t in deltas.items()}
         self.base = {n: unet.w[n].clone() for n in self.delta}

@@ -15,7 +15,7 @@ import torch
 
 from . import ops
 from .config import TEXT_SEQ_LEN, depth_at, heads_at, unet_config, vae_config
-from .packing import pack_conv1x1, pack_conv3x3, pack_conv3x3_up2, pack_geglu
+from .packing import pack_conv1x1, pack_conv3x3, pack_conv3x3_up2, pack_ff2_cols, pack_geglu
 
 
 import os
@@ -329,7 +329,7 @@ class UNetHip(_Net):
             self._put(q + ".o2.w", sd[f"{t}.attn2.to_out.0.weight"])
             self._put(q + ".o2.b", sd[f"{t}.attn2.to_out.0.bias"])
             kv_list.append((q, sd[f"{t}.attn2.to_k.weight"], sd[f"{t}.attn2.to_v.weight"]))
-            self._put(q + ".ff2.w", sd[f"{t}.ff.net.2.weight"])
+            self._put(q + ".ff2.w", pack_ff2_cols(sd[f"{t}.ff.net.2.weight"]))      # columns in the GEGLU output's stored order
             self._put(q + ".ff2.b", sd[f"{t}.ff.net.2.bias"])
 
     # ---- per request: cross-attention K/V of all 16 layers (depend on the prompt only) -------
@@ -438,6 +438,11 @@ class UNetHip(_Net):
             ops.attention(q2, kv_all[:, off:off + C], kv_all[:, off + C:off + 2 * C], a, B, heads, HW, TEXT_SEQ_LEN, d,
                           ldq=C, ldk=self.kv_total, ldv=self.kv_total, ldo=C, scale=0.0 if Q_PRESCALE else None)
             ops.gemm(a, w[q + ".o2.w"], h, bias=w[q + ".o2.b"], res=h, img_rows=HW)
+            if LN_FOLD and ops.mlp_fused_applies(M, C, HW):
+                # norm3 -> ff.net.0 -> GEGLU -> ff.net.2 -> + h as ONE kernel: the [M, 4C] intermediate stays on the CU.  A launch
+                # parameter like the tile shape: chosen from the total row count, bit-identical to the two launches below
+                ops.mlp_geglu(h, w[q + ".ff1.w"], w[q + ".ff1.g"], w[q + ".ff1.c"], w[q + ".ff2.w"], w[q + ".ff2.b"], h, img_rows=HW)
+                continue
             if LN_FOLD:
                 ops.gemm_ln(h, w[q + ".ff1.w"], w[q + ".ff1.g"], w[q + ".ff1.c"], ff, epilogue=1, img_rows=HW)
             else:

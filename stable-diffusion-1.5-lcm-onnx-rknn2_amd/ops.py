@@ -184,6 +184,37 @@ def gemm_ln(a, w, ln_g, ln_c, out, *, eps=1e-5, epilogue=0, img_rows=0):
     return out
 
 
+import os as _os
+
+_MLP_FUSED_MIN_ROWS = int(_os.environ.get("LCM_MLP_FUSED_MIN_ROWS", "24576") or 0)      # 0 switches the fused kernel off
+
+
+def mlp_fused_applies(M, C, img_rows):
+    """Whether the FeedForward of a transformer block runs as the one fused kernel (csrc/mlp_fused.hip): C = 320 (its register
+    budget), enough rows to give most CUs a 128-row workgroup (24 576 = 192 workgroups: batches of 6 and more at 512x512),
+    and a layer whose canonical K partition of ff.net.2 has one part (the fused kernel accumulates one).  Bit-identical to the
+    two-launch form, so -- like a tile shape -- it may follow the batch."""
+    if _MLP_FUSED_MIN_ROWS <= 0 or C != 320 or M < _MLP_FUSED_MIN_ROWS:
+        return False
+    m_img = img_rows if img_rows and M % img_rows == 0 else M
+    return canonical_splits(0, m_img, C, 4 * C, 1, 0) == 1
+
+
+def mlp_geglu(x, w1, ln_g, ln_c, w2, b2, out, *, eps=1e-5, img_rows=0):
+    """out = x + Linear_2(GEGLU(Linear_1(LayerNorm(x)))) in one launch (include/lcm_hip.h, lcm_mlp_geglu_f16); out may be x."""
+    L = _lib.load()
+    M, Cc = x.shape
+    F = w2.shape[1]
+    RECORD = _record_list()
+    if RECORD is not None:          # nothing to tune (no tile / variant choice): recorded for the replay legs only
+        RECORD.append((None, None, lambda: mlp_geglu(x, w1, ln_g, ln_c, w2, b2, out, eps=eps, img_rows=img_rows)))
+    with _Timed("mlp", "fused", 2.0 * M * (2 * F) * Cc + 2.0 * M * Cc * F, 2.0 * (2 * M * Cc + 2 * F * Cc + Cc * F)):
+        rc = L.lcm_mlp_geglu_f16(_p(x), x.stride(0), _p(w1), _p(ln_g), _p(ln_c), float(eps), _p(w2), _p(b2), _p(out),
+                                 out.stride(0), M, Cc, int(img_rows), _stream())
+    _lib.check(rc, "lcm_mlp_geglu_f16")
+    return out
+
+
 def ln_fold_refresh(w, g_out, c_base=None, c_delta=None, alpha=0.0, c_out=None):
     _lib.check(_lib.load().lcm_ln_fold_refresh(_p(w), w.shape[0], w.shape[1], _p(c_base), _p(c_delta), float(alpha), _p(g_out),
                                                _p(c_out), _stream()), "lcm_ln_fold_refresh")

@@ -4,6 +4,9 @@
 * 1x1 conv / linear         -> [N][K] as is
 * GEGLU proj (value|gate)   -> rows interleaved in blocks of 16 so value/gate of one output column land in
                                the same lane of adjacent MFMA tiles (csrc/igemm.hip epilogue)
+* GEGLU output / ff.net.2   -> the [M][F] intermediate is stored in "operand order" (geglu_col_order): ff.net.2's columns are
+                               permuted alike, so the fused FeedForward kernel (csrc/mlp_fused.hip) and the two-launch form
+                               multiply the same values in the same MFMA k slots
 * to_q|to_k|to_v            -> one [3C][C] matrix; cross-attention to_k|to_v -> [2C][768]
 """
 from __future__ import annotations
@@ -54,3 +57,19 @@ def pack_geglu(w: torch.Tensor, b: torch.Tensor | None):
     if b is not None:
         bp = torch.stack([b[:Fh].reshape(-1, 16), b[Fh:].reshape(-1, 16)], dim=1).reshape(F2).contiguous()
     return wp, bp
+
+
+def geglu_col_order(F: int) -> torch.Tensor:
+    """order[s] = value channel stored at column s of the GEGLU output (csrc/igemm_common.h geglu_store_col): channel
+    16 P + 4 fq + j sits at 32 (P >> 1) + 8 fq + 4 (P & 1) + j -- 8 consecutive columns are what one lane of the producing MFMA
+    tiles holds (the quads of value/gate pairs 2u and 2u + 1)."""
+    assert F % 32 == 0
+    s = torch.arange(F)
+    u, r = s // 32, s % 32
+    fq, par, j = r // 8, (r % 8) // 4, r % 4
+    return 16 * (2 * u + par) + 4 * fq + j
+
+
+def pack_ff2_cols(w: torch.Tensor) -> torch.Tensor:
+    """ff.net.2 weight [C][F] (or any delta of it) with its columns in the stored order of the GEGLU output."""
+    return w[:, geglu_col_order(w.shape[1]).to(w.device)].contiguous()

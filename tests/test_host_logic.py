@@ -122,6 +122,17 @@ def test_packing_layouts():
         assert torch.equal(wp[32 * q:32 * q + 16], wg[16 * q:16 * q + 16])
         assert torch.equal(wp[32 * q + 16:32 * q + 32], wg[32 + 16 * q:32 + 16 * q + 16])
         assert torch.equal(bp[32 * q + 16:32 * q + 32], bg[32 + 16 * q:32 + 16 * q + 16])
+    # GEGLU output / ff.net.2 columns in operand order: a permutation; channel 16P + 4fq + j at column 32(P>>1) + 8fq + 4(P&1) + j
+    # (csrc/igemm_common.h geglu_store_col); 8 consecutive columns = the two quads one MFMA lane holds
+    from sdlcm_amd.packing import geglu_col_order, pack_ff2_cols
+    order = geglu_col_order(1280)
+    assert sorted(order.tolist()) == list(range(1280))
+    for ch in (0, 5, 17, 36, 1279):
+        P, fq, j = ch // 16, (ch % 16) // 4, ch % 4
+        assert order[32 * (P >> 1) + 8 * fq + 4 * (P & 1) + j] == ch
+    assert order[:8].tolist() == [0, 1, 2, 3, 16, 17, 18, 19]
+    w2 = torch.arange(3 * 64, dtype=torch.float32).reshape(3, 64)
+    assert torch.equal(pack_ff2_cols(w2)[:, :8], w2[:, [0, 1, 2, 3, 16, 17, 18, 19]])
 
 
 def test_worker_interface_mirror_and_errors(monkeypatch):

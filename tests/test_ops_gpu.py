@@ -78,7 +78,8 @@ def test_gemm_geglu():
     out = torch.empty(M, 4 * C, dtype=torch.float16, device=DEV)
     ops.gemm(a.to(DEV), wp.to(DEV), out, bias=bp.to(DEV), epilogue=1)
     h, g = F.linear(a.float(), w.float(), b.float()).chunk(2, dim=-1)
-    close(out, h * F.gelu(g), what="geglu")
+    from sdlcm_amd.packing import geglu_col_order
+    close(out, (h * F.gelu(g))[:, geglu_col_order(4 * C)], what="geglu")       # stored in operand order (packing.geglu_col_order)
 
 
 def test_gemm_batched_strided():
@@ -1022,8 +1023,9 @@ def test_gemm_with_folded_layernorm(M, C, N, geglu, bias):
     Wg = W.float() * gamma.float()[None, :]
     c = W.float() @ beta.float() + (b.float() if bias else 0.0)
     if geglu:
+        from sdlcm_amd.packing import geglu_col_order
         val, gate = ref.chunk(2, dim=1)
-        ref = val * F.gelu(gate)
+        ref = (val * F.gelu(gate))[:, geglu_col_order(N // 2)]             # the GEGLU output is stored in operand order
         Wg, c = pack_geglu(Wg, c)
     Wh = Wg.half()
     g = Wh.float().sum(1)
@@ -1193,3 +1195,58 @@ def test_lane_streams_are_never_recycled_handles():
     assert {s.cuda_stream for s in again} == handles
     for s in again:
         ops.release_stream(s)
+
+
+@pytest.mark.parametrize("M,img", [(32768, 4096), (24576 + 77, 0), (36864, 9216)])
+def test_fused_mlp_is_bit_identical_to_two_launches(M, img):
+    """norm3 -> ff.net.0 -> GEGLU -> ff.net.2 -> + h as ONE kernel (lcm_mlp_geglu_f16, csrc/mlp_fused.hip) against the two launches
+    it replaces (lcm_gemm_ln_f16 with the GEGLU epilogue, lcm_gemm_f16 with bias + residual): the same bits -- the kernel is a
+    launch parameter chosen from the row count, like a tile shape -- and both against the torch fp32 reference of
+    h + Linear(GEGLU(Linear(LayerNorm(h)))).  Ragged last workgroup (M % 128 != 0), in-place output, rows with a common offset."""
+    from sdlcm_amd.packing import pack_ff2_cols, pack_geglu
+    C, Fh = 320, 1280
+    x = (rnd(M, C, seed=1).float() * 0.7 + 0.5 + rnd(M, 1, seed=8).float()).half()
+    gamma, beta = (1 + 0.2 * rnd(C, seed=2).float()).half(), rnd(C, seed=3, scale=0.2)
+    W1, b1 = rnd(2 * Fh, C, seed=4, scale=C ** -0.5), rnd(2 * Fh, seed=5, scale=0.3)
+    W2, b2 = rnd(C, Fh, seed=6, scale=Fh ** -0.5), rnd(C, seed=7, scale=0.3)
+    Wg = W1.float() * gamma.float()[None, :]
+    c = W1.float() @ beta.float() + b1.float()
+    Wg, c = pack_geglu(Wg, c)
+    W1h = Wg.half().to(DEV)
+    g = torch.zeros(2 * Fh, dtype=torch.float32, device=DEV)
+    ops.ln_fold_refresh(W1h, g)
+    c, W2p, b2d = c.to(DEV), pack_ff2_cols(W2).to(DEV), b2.to(DEV)
+    # two launches
+    h2 = x.to(DEV).clone()
+    ff = torch.empty(M, Fh, dtype=torch.float16, device=DEV)
+    ops.gemm_ln(h2, W1h, g, c, ff, epilogue=1, img_rows=img)
+    ops.gemm(ff, W2p, h2, bias=b2d, res=h2, img_rows=img)
+    # one launch, in place
+    h1 = x.to(DEV).clone()
+    guard = torch.full((4096,), 7.0, dtype=torch.float16, device=DEV)
+    assert ops.mlp_fused_applies(M, C, img)
+    ops.mlp_geglu(h1, W1h, g, c, W2p, b2d, h1, img_rows=img)
+    torch.cuda.synchronize()
+    assert torch.equal(h1, h2), f"fused FeedForward differs from the two launches: max |d| = {(h1.float() - h2.float()).abs().max().item():.3g}"
+    assert bool((guard == 7.0).all())
+    # against torch fp32 on a sample of rows (first / last workgroups, the ragged tail)
+    rows = torch.cat([torch.arange(0, 256), torch.arange(M // 2, M // 2 + 128), torch.arange(M - 200, M)])
+    xr = x[rows].float()
+    v, gt = F.linear(F.layer_norm(xr, (C,), gamma.float(), beta.float(), 1e-5), W1.float(), b1.float()).chunk(2, dim=1)
+    ref = xr + F.linear((v * F.gelu(gt)).half().float(), W2.float(), b2.float())
+    close(h1[rows.to(DEV)], ref, rtol=6e-3, what="fused FeedForward")
+
+
+def test_fused_mlp_refuses_what_it_cannot_reproduce():
+    """Layers whose canonical K partition of ff.net.2 has parts (small images), and widths other than 320, take the two launches:
+    the selector says no and the C ABI refuses with a message instead of computing something else."""
+    from sdlcm_amd.lib import LcmHipError
+    assert not ops.mlp_fused_applies(32768, 640, 1024)
+    assert not ops.mlp_fused_applies(1024, 320, 1024)              # too few rows
+    parts = ops.canonical_splits(0, 256, 320, 1280, 1, 0)
+    assert parts > 1 and not ops.mlp_fused_applies(32768, 320, 256)
+    x = torch.zeros(32768, 320, dtype=torch.float16, device=DEV)
+    w1, w2 = torch.zeros(2560, 320, dtype=torch.float16, device=DEV), torch.zeros(320, 1280, dtype=torch.float16, device=DEV)
+    z = torch.zeros(2560, dtype=torch.float32, device=DEV)
+    with pytest.raises(LcmHipError, match="canonical K partition"):
+        ops.mlp_geglu(x, w1, z, z, w2, None, x, img_rows=256)
