@@ -107,41 +107,59 @@ def roofline_leg(pipe, P, guidance, ms_per_step):
             "mfma_flop_per_pass": round(tot_f), "by_kernel": table}
     out["algorithmic_bytes_per_launch_avg"] = round(dom["bytes"] / dom["n"])     # operands + result, each counted once
     out.update(_pmc_counters(name.replace(" +splitk", "")))
+    # `bound` names the roof `achieved` / `peak` are quoted against (a contraction: MFMA).  Which resource actually limits the
+    # launch is a separate statement, made from the counters when they are fresh: neither roof within 25 % = latency
+    hb = out.get("hbm_gbs")
+    fr_m, fr_h = out["frac"], (hb / HBM_PEAK_GBS if hb else None)
+    out["limiting"] = ("unknown (no fresh counters)" if fr_h is None else
+                       "mfma" if fr_m >= 0.25 and fr_m >= fr_h else "hbm" if fr_h >= 0.25 else
+                       f"latency (mfma {fr_m:.0%} and hbm {fr_h:.0%} of their roofs: a chain of short dependent launches)")
     out["traffic_unit"] = "bytes per launch (fabric reads + writes)"
     out["traffic_source"] = traffic_src
     out["kernel_launches_per_pass"] = len(times)
     return out
 
 
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic.json")
-PMC_SUMMARY_FILE = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_traffic.json")
+PMC_SUMMARY_FILE = os.path.join(ROOT, "profiles", "r04_pmc_summary.json")
 
 
 def _pmc_counters(kernel_name):
     """MFMA-busy fraction and HBM GB/s of the dominant kernel from the committed rocprofv3 --pmc passes over an eager
-    single-kernel target of the same shape class (profiles/r03_pmc_summary.json <- tools/pmc_round3.sh + tools/pmc_summary.py;
-    counters cannot be read from inside this process).  Absent kernel: the fields are null and the reason is given."""
+    single-kernel target of the same shape class (profiles/r04_pmc_summary.json <- tools/pmc_round4.sh + tools/pmc_summary.py;
+    counters cannot be read from inside this process).  The entry must match the instantiation UNIQUELY and must have been taken
+    on the kernel sources of this tree (its recorded sha256, tools/check_profiles_fresh.py): otherwise the fields are null and the
+    reason is given -- a counter of another kernel, or of an older build of this one, is never reported."""
     import json
+    none = {"mfma_busy_frac": None, "hbm_gbs": None}
     try:
         with open(PMC_SUMMARY_FILE) as f:
             tab = json.load(f)
     except Exception as e:
-        return {"mfma_busy_frac": None, "hbm_gbs": None, "pmc_source": f"{os.path.relpath(PMC_SUMMARY_FILE, ROOT)} unreadable ({e!r})"}
-    key = kernel_name.rstrip(">").strip()
-    for k, v in tab.items():
-        if k.rstrip(">").strip().startswith(key):
-            clk = v.get("effective_clock_ghz")
-            if clk is not None and clk > 2.5 and v.get("mfma_busy_frac_at_2p1ghz") is not None:
-                # launches of a few microseconds: GRBM_GUI_ACTIVE also counts the dispatch around the kernel (an "effective clock"
-                # above the chip's 2.4 GHz), so the busy cycles are taken over the kernel's own duration at 2.1 GHz instead
-                return {"mfma_busy_frac": v["mfma_busy_frac_at_2p1ghz"], "hbm_gbs": v["hbm_gbs"], "effective_clock_ghz": None,
-                        "pmc_source": f"{v['source']} ({v['what']}): SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs over the kernel's duration x 2.1 GHz "
-                                      f"(GRBM_GUI_ACTIVE over-counts launches this short); (2 x FETCH_SIZE + WRITE_SIZE) / kernel time"}
-            return {"mfma_busy_frac": v["mfma_busy_frac"], "hbm_gbs": v["hbm_gbs"], "effective_clock_ghz": clk,
-                    "pmc_source": f"{v['source']} ({v['what']}): SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs over GRBM_GUI_ACTIVE / 8 XCDs; "
-                                  f"(2 x FETCH_SIZE + WRITE_SIZE) / kernel time"}
-    return {"mfma_busy_frac": None, "hbm_gbs": None,
-            "pmc_source": f"kernel '{kernel_name}' is not in {os.path.relpath(PMC_SUMMARY_FILE, ROOT)} (has {sorted(tab)}): run tools/pmc_round3.sh"}
+        return dict(none, pmc_source=f"{os.path.relpath(PMC_SUMMARY_FILE, ROOT)} unreadable ({e!r})")
+    key = kernel_name.strip()
+    hits = [k for k in tab if k.strip() == key] or [k for k in tab if k.rstrip(">").strip().startswith(key.rstrip(">").strip() + ",") or k.strip().startswith(key)]
+    if len(hits) != 1:
+        return dict(none, pmc_source=f"kernel '{kernel_name}' matches {len(hits)} entries of {os.path.relpath(PMC_SUMMARY_FILE, ROOT)} "
+                                     f"(has {sorted(tab)}): run tools/pmc_round4.sh")
+    try:
+        from tools.check_profiles_fresh import stale_entries
+        stale = stale_entries(PMC_SUMMARY_FILE).get(hits[0])
+    except Exception as e:
+        stale = f"freshness check failed ({e!r})"
+    if stale:
+        return dict(none, pmc_source=f"{os.path.relpath(PMC_SUMMARY_FILE, ROOT)}['{hits[0]}'] is stale: {stale}")
+    v = tab[hits[0]]
+    clk = v.get("effective_clock_ghz")
+    if clk is not None and clk > 2.5 and v.get("mfma_busy_frac_at_2p1ghz") is not None:
+        # launches of a few microseconds: GRBM_GUI_ACTIVE also counts the dispatch around the kernel (an "effective clock"
+        # above the chip's 2.4 GHz), so the busy cycles are taken over the kernel's own duration at 2.1 GHz instead
+        return {"mfma_busy_frac": v["mfma_busy_frac_at_2p1ghz"], "hbm_gbs": v["hbm_gbs"], "effective_clock_ghz": None,
+                "pmc_source": f"{v['source']} ({v['what']}): SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs over the kernel's duration x 2.1 GHz "
+                              f"(GRBM_GUI_ACTIVE over-counts launches this short); (2 x FETCH_SIZE + WRITE_SIZE) / kernel time"}
+    return {"mfma_busy_frac": v["mfma_busy_frac"], "hbm_gbs": v["hbm_gbs"], "effective_clock_ghz": clk,
+            "pmc_source": f"{v['source']} ({v['what']}): SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs over GRBM_GUI_ACTIVE / 8 XCDs; "
+                          f"(2 x FETCH_SIZE + WRITE_SIZE) / kernel time"}
 
 
 def _pmc_traffic(kernel_name, batch):
@@ -379,11 +397,14 @@ def main():
             outs.append(e.forward(ids, output="penultimate") if len(enc) > 1 else e.forward(ids))
         return torch.cat(outs, dim=-1) if len(outs) > 1 else outs[0]
 
-    def prime(Bx, lane=0, pl=None, hh=None, ww=None, nn=None):
-        """Fill a plan's resident inputs: embeddings from rank 0's prompt encoder, broadcast over RCCL; per-request noise."""
+    def prime(Bx, lane=0, pl=None, hh=None, ww=None, nn=None, cfg=None):
+        """Fill a plan's resident inputs: embeddings from rank 0's prompt encoder, broadcast over RCCL; per-request noise.
+        cfg: a guidance scale > 1 = classifier-free guidance (UNet batch 2 Bx: rows [0, Bx) the negative conditioning = zeros,
+        the reference's force_zeros_for_empty_prompt, rows [Bx, 2 Bx) the prompt)."""
         pl = pl or pipe
         hh, ww, nn = hh or h, ww or w, nn or n
-        P = pl.plan(Bx, hh, ww, nn, lane=lane)
+        gd = float(cfg) if cfg else 1.0
+        P = pl.plan(Bx, hh, ww, nn, do_cfg=bool(cfg), guidance=gd if cfg else None, lane=lane)
         with torch.cuda.stream(P.lane.stream):
             allpe = prompt_embeddings(pl, world * Bx) if rank == 0 else None
             if dist is not None:
@@ -405,12 +426,14 @@ def main():
                         torch.cuda.synchronize()
                         bcast_ms[Bx] = (time.perf_counter() - tb) * 1e3
                 allpe = got
-            P.ehs.copy_(allpe[rank * Bx:(rank + 1) * Bx].reshape(Bx * 77, pl.unet.ctx_dim))
+            P.ehs[(P.UB - Bx) * 77:].copy_(allpe[rank * Bx:(rank + 1) * Bx].reshape(Bx * 77, pl.unet.ctx_dim))
             if pl.unet.has_added:      # SDXL: pooled text embedding + size/crop ids
                 from sdlcm_amd.pipeline import sinusoid_host
                 pooled = torch.randn(Bx, pl.unet.added_dim - 6 * 256, generator=torch.Generator().manual_seed(2))
                 tid = torch.from_numpy(sinusoid_host(np.array([8 * hh, 8 * ww, 0, 0, 8 * hh, 8 * ww] * Bx, np.float32), 256)).reshape(Bx, -1)
-                P.add_in.copy_(torch.cat([pooled, tid], 1).half())
+                P.add_in[P.UB - Bx:].copy_(torch.cat([pooled, tid], 1).half())
+                if cfg:
+                    P.add_in[:Bx].copy_(torch.cat([torch.zeros_like(pooled), tid], 1).half())
             for b in range(Bx):
                 l0, extra = draw_noise(1000 + rank * Bx + b, hh, ww, nn - 1)
                 P.lat0[b].copy_(l0[0])
@@ -418,12 +441,12 @@ def main():
                     P.noise[i, b].copy_(e[0])
             P.wemb.copy_(torch.from_numpy(guidance_scale_embedding(np.zeros(Bx, np.float32), P.wemb.shape[1])).half())
             pl.tune(P)                                 # per-shape launch autotune (once)
-            pl._enqueue(P, 1.0)                        # eager warm-up: allocates scratch
+            pl._enqueue(P, gd)                         # eager warm-up: allocates scratch
             P.lane.stream.synchronize()
             from sdlcm_amd import ops
             g = ops.Graph()
             with g:
-                pl._enqueue(P, 1.0)
+                pl._enqueue(P, gd)
             P.graph = g
         return P
 
@@ -586,6 +609,16 @@ def main():
                                   "pipeline_tflops": round(flx / (dtx / 2) / 1e12, 1),
                                   "workload": "SDXL-base architecture 1024x1024, 30 steps, batch 1, guidance 1.0 (no CFG: UNet batch 1), fp16 "
                                               "VAE with residual-stream rescaling (BASELINE configs[4]; 213 TFLOP per image, SURVEY 8d)"}
+            if os.environ.get("LCM_BENCH_SDXL_CFG", "1") != "0":
+                # the reference's own SDXL mode default: guidance 7.5 (modes.yaml.example:48-54) => classifier-free guidance,
+                # every UNet forward runs on [negative | prompt] = batch 2; the VAE decodes batch 1
+                Pc = prime(1, pl=xl, hh=128, ww=128, nn=30, cfg=7.5)
+                dtc, _ = timed(Pc, 2, 1)
+                flc = 2 * 6.761e12 * 30 + 10.470e12
+                line["extra_sdxl_cfg"] = {"images_per_s": round(2 / dtc, 4), "ms_per_step": round(dtc / 2 * 1e3, 1),
+                                          "pipeline_tflops": round(flc / (dtc / 2) / 1e12, 1),
+                                          "workload": "SDXL-base architecture 1024x1024, 30 steps, batch 1, guidance 7.5 (classifier-free guidance: "
+                                                      "UNet batch 2; the reference's sdxl mode default, modes.yaml.example:48-54); 416 TFLOP per image"}
             xl.close()
     emit_line(real_stdout, line if rank == 0 else None)
     if dist is not None:

@@ -187,6 +187,9 @@ int lcm_set_halo_pipe_threshold(int wgs);
 /* GroupNorm-fused convolution (lcm_conv3x3_gn_f16 with scale / shift): 1 = the raw halo of the next 64-channel chunk
  * is fetched into registers under the taps of the current one (measured slower: 202 VGPRs, two workgroups per CU instead of three), 0 (default) = fetched where it is consumed.  Bit-neutral. */
 int lcm_set_halo_prefetch(int on);
+/* 1 (default): the LDS-halo convolution's plain (unsplit) launches fetch the residual tile by LDS-DMA and store the result tile
+ * in whole rows through an LDS image of the tile; 0: 8-byte pieces per lane.  Bit-neutral. */
+int lcm_set_staged_epilogue(int on);
 /* 1 (default): stride-1 3x3 convolutions use the LDS-halo kernel; 0: the row-gather implicit GEMM everywhere */
 int lcm_set_conv_impl(int impl);
 
@@ -307,6 +310,10 @@ int lcm_profile_begin(int max_launches);
 int lcm_profile_end(char* out, int64_t cap);
 /* profiling aid: hold the stream busy for `usec` (<= 2 s) so queued launches run back to back */
 int lcm_debug_spin(int usec, void* stream);
+/* measurement only (tools/seam_cost.py): n_barriers grid-wide seams (release, one monotonic counter, bounded relaxed poll, acquire,
+ * re-read of another workgroup's 128-byte record) inside ONE launch of `workgroups` <= 256 co-resident workgroups; state = device
+ * memory of >= 16 + workgroups * 128 bytes (word 1 reads 1 afterwards if a spin gave up).  Never on the product path. */
+int lcm_debug_grid_barrier(int workgroups, int n_barriers, void* state, void* stream);
 
 /* ---- AutoencoderKL.tiled_decode glue (vae.enable_tiling(), backends/cuda_worker.py:91): decoded tiles are fp32
  * pixel-major [B,h,w,3].  blend: vertical=1 -> b[y] = a[ah-extent+y]*(1-y/extent) + b[y]*(y/extent) for y < extent (aw == bw);

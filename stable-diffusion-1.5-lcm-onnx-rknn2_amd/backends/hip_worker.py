@@ -9,8 +9,8 @@ Env (as the reference, backends/cuda_worker.py:43-61):
                       LCM_HIP_SYNTHETIC=1) selects seeded synthetic weights of the SD1.5 architecture --
                       no checkpoint ships with the reference.
   CUDA_DEVICE / HIP_DEVICE   default cuda:0 (torch's name for the HIP device)
-  CUDA_DTYPE                 fp16 | bf16 | fp32 accepted as the reference does; the kernels always run fp16 operands with
-                             fp32 accumulation (within tolerance of the fp32 pipeline)
+  CUDA_DTYPE                 fp16 (default).  bf16 / fp32 -- which the reference honours -- are REFUSED unless LCM_HIP_DTYPE=fp16
+                             says to run them in this backend's one arithmetic (fp16 operands, fp32 accumulation)
 """
 from __future__ import annotations
 
@@ -304,12 +304,14 @@ class HipLcmWorker:
         dtype_str = os.environ.get("CUDA_DTYPE", "fp16").lower().strip()
         if dtype_str not in ("fp16", "bf16", "fp32"):
             raise RuntimeError(f"Unknown CUDA_DTYPE={dtype_str}, expected fp16, bf16 or fp32")      # cuda_worker.py:55-61
-        if dtype_str != "fp16":
-            # the reference's other two settings are accepted, not honoured as storage types: the HIP kernels keep fp16
-            # operands with fp32 accumulation and fp32 sampler state, which is inside the north_star tolerance of the
-            # reference's fp32 pipeline (the parity tests compare against an fp32 oracle)
-            print(f"[hip] CUDA_DTYPE={dtype_str}: the HIP backend computes with fp16 operands / fp32 accumulation "
-                  f"(max |delta| vs the fp32 reference pipeline < 1e-2 on the decoded image)")
+        if dtype_str != "fp16" and os.environ.get("LCM_HIP_DTYPE", "").lower().strip() != "fp16":
+            # The reference honours bf16 / fp32 (torch dtype of the whole pipeline, cuda_worker.py:55-61).  This backend has ONE
+            # arithmetic: fp16 operands, fp32 accumulation, fp32 sampler state -- inside north_star's tolerance of the fp32 pipeline
+            # (max |delta| < 1e-2 on the decoded image; measured ~2e-3), but not what the setting asks for.  So it is refused,
+            # not silently reinterpreted; LCM_HIP_DTYPE=fp16 states the override explicitly.
+            raise RuntimeError(f"CUDA_DTYPE={dtype_str} is not available with BACKEND=hip: the HIP kernels compute with fp16 operands and "
+                               f"fp32 accumulation only.  Set CUDA_DTYPE=fp16, or LCM_HIP_DTYPE=fp16 to run this mode in that arithmetic "
+                               f"(max |delta| vs the fp32 pipeline < 1e-2 on the decoded image)")
         if not torch.cuda.is_available():
             raise LcmHipError("HipLcmWorker needs an MI355X; no CPU fallback exists on this path")
         from .worker_factory import pick_device

@@ -64,9 +64,29 @@ def pick_device(worker_id: int, device_count: int, env=None) -> str:
     return (env.get("HIP_DEVICE") or env.get("CUDA_DEVICE") or "cuda:0").strip()
 
 
+_POOL_QUEUE = None          # weakref to the queue the caller's single consumer thread takes jobs from (set_pool_queue)
+
+
+def set_pool_queue(q, worker=None) -> None:
+    """For a ``WorkerPool`` built by hand (dependency injection; ``get_worker_pool()`` is found without this): name its job
+    queue ONCE -- ``set_pool_queue(pool.q, pool._worker)`` -- and every worker this factory creates afterwards (mode switches
+    re-create it, backends/worker_pool.py:316-320) drains that queue into batched passes (``HipLcmWorker.run_job``).
+    ``worker``: the one the pool's constructor already created.  ``q=None`` forgets the queue."""
+    global _POOL_QUEUE
+    import weakref
+    _POOL_QUEUE = weakref.ref(q) if q is not None else None
+    if worker is not None and hasattr(worker, "bind_queue"):
+        worker.bind_queue(q)
+
+
 def create_hip_worker(worker_id: int):
     kind = detect_worker_type()
     from .hip_worker import HipLcmSDXLWorker, HipLcmWorker
     if kind == "sdxl":
-        return HipLcmSDXLWorker(worker_id=worker_id)                 # backends/worker_factory.py:93
-    return HipLcmWorker(worker_id=worker_id)                         # backends/worker_factory.py:97
+        w = HipLcmSDXLWorker(worker_id=worker_id)                    # backends/worker_factory.py:93
+    else:
+        w = HipLcmWorker(worker_id=worker_id)                        # backends/worker_factory.py:97
+    q = _POOL_QUEUE() if _POOL_QUEUE is not None else None
+    if q is not None:
+        w.bind_queue(q)
+    return w

@@ -927,6 +927,7 @@ struct HaloParams {
     int silu;
     int H, W;
     int tiles_y, tiles_x;
+    int staged_epi;
 };
 int lcm_conv_halo_launch(HaloParams& hp, int B, hipStream_t s, int* slabs_per_image);
 

@@ -106,11 +106,23 @@ __device__ __forceinline__ h4 geglu_ln_quad(f4 x, f4 g, float ln_r, float ln_mu,
 // registers (mlp_fused.hip).
 __device__ __forceinline__ int geglu_store_col(int P, int fq) { return 32 * (P >> 1) + 8 * fq + 4 * (P & 1); }
 
-template <int BM, int BN>
+// Position of 16-byte chunk c of tile pixel q in the LDS staging image of an output tile ([pixel][CH chunks], CH = BN / 8): the
+// chunks of a pixel are rotated by the pixel index so that the 16 pixels a wave touches at once fall on 16 different slots
+// (the rows are a multiple of 128 bytes long: unrotated, every pixel's chunk c sits on the same banks).
+template <int CH>
+__device__ __forceinline__ int stage_pos(int c, int q) { return (c + q) % CH; }
+template <int CH>
+__device__ __forceinline__ int stage_src(int cpos, int q) { return (cpos + CH - q % CH) % CH; }
+
+// STAGED = 1: the residual tile is READ from, and the result tile WRITTEN to, an LDS image of the output tile (`stage`, BM x BN
+// fp16, stage_pos layout; tile_epilogue_staged fills it by LDS-DMA beforehand and copies it out in whole rows afterwards) instead
+// of global memory in 8-byte pieces per lane.  The arithmetic is this one function either way.
+template <int BM, int BN, int STAGED = 0>
 __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f4 (&acc)[BN / 32][BM / 32], const int (&m_of)[BM / 32],
                                                int n_wave, int fq, int z, const int (&slab_of)[BM / 64],
                                                const float* ln_mu = nullptr, const float* ln_r = nullptr,
-                                               const __attribute__((address_space(3))) float* ln_lds = nullptr, int n_tile0 = 0) {
+                                               const __attribute__((address_space(3))) float* ln_lds = nullptr, int n_tile0 = 0,
+                                               char* stage = nullptr, int q_wave = 0, int nl_wave = 0) {
     // ln_lds: the BN entries of ln_g then of ln_c of this n-tile (first channel n_tile0), staged in LDS by the kernel --
     // an ordinary global load here, inside the K loop of a kernel that keeps LDS-DMA in flight, makes the compiler drain
     // the DMA ring (s_waitcnt vmcnt(0)) in front of every fragment read
@@ -181,10 +193,19 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmParams& p, f4 (&acc)[B
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v[j] = gelu_erf_f(v[j]);
                     }
-                    if (p.res) { h4 t = *reinterpret_cast<const h4*>(p.res + (long long)m * p.ldr + n);
+                    int soff = 0;
+                    if constexpr (STAGED != 0) {
+                        const int q = q_wave + b * 16 + (lane & 15), nl = nl_wave + a * 16 + fq * 4;
+                        soff = q * (BN * 2) + stage_pos<BN / 8>(nl >> 3, q) * 16 + (nl & 4) * 2;
+                    }
+                    if (p.res) {
+                        h4 t;
+                        if constexpr (STAGED != 0) t = *reinterpret_cast<const h4*>(stage + soff);
+                        else t = *reinterpret_cast<const h4*>(p.res + (long long)m * p.ldr + n);
                         v[0] += (float)t[0]; v[1] += (float)t[1]; v[2] += (float)t[2]; v[3] += (float)t[3]; }
                     h4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-                    *reinterpret_cast<h4*>(outb + (long long)m * p.ldo + n) = o;
+                    if constexpr (STAGED != 0) *reinterpret_cast<h4*>(stage + soff) = o;
+                    else *reinterpret_cast<h4*>(outb + (long long)m * p.ldo + n) = o;
                     if (do_stats) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) { const float f = (float)o[j]; ssum[j] += f; ssq[j] += f * f; }
@@ -239,6 +260,53 @@ row16_sum8(ssum, ssq);
                 }
                 *reinterpret_cast<h4*>(outb + (long long)m * p.ldo + nout) = o;
             }
+        }
+    }
+}
+
+// The epilogue of a whole output tile with its global traffic in whole rows (plain launches: splits == 1, epi == 0, no LayerNorm
+// fold).  The per-lane form above moves the residual and the result in 8-byte pieces, 16 rows x 32 bytes per wave instruction:
+// 4x the cache lines per instruction of a full-row access, and twice the store instructions -- the residual of the 512x512
+// AutoencoderKL conv2 launches cost +27 % of the kernel that way.  Here: (1) the residual tile arrives by
+// LDS-DMA (16 bytes per lane, full 128-byte lines, no VGPRs) into `stage`, an image of the tile laid over the K loop's dead LDS
+// buffers; (2) igemm_epilogue<.., 1> reads it from there and writes the fp16 results back into the same cells (each cell is
+// read and written by ONE lane); (3) every thread copies 16-byte pieces out, 16 consecutive lanes covering one pixel's row.
+// row_of(q) -> global output row of tile pixel q, or -1.  The arithmetic, the statistics and their order are those of the
+// per-lane form: bit-identical (tests/test_ops_gpu.py::test_staged_epilogue_is_bit_identical).
+static __device__ __attribute__((aligned(256))) half_t g_zero_page_epi[128];
+
+template <int BM, int BN, class RowOf>
+__device__ __forceinline__ void tile_epilogue_staged(const IgemmParams& p, f4 (&acc)[BN / 32][BM / 32], const int (&m_of)[BM / 32],
+                                                     int n_base, int wm, int wn, int fq, const int (&slab_of)[BM / 64],
+                                                     char* stage, RowOf row_of) {
+    constexpr int CH = BN / 8, PIECES = BM * CH, NV = (PIECES + 255) / 256;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    __syncthreads();                              // every wave is done with the K loop's LDS tiles
+    if (p.res) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            if ((wave + 4 * i) * 64 < PIECES) {   // wave-uniform: whole 1 KiB piece in range (PIECES is a multiple of 64)
+                const int v = tid + 256 * i, q = v / CH, cpos = v - q * CH;
+                const int m = row_of(q);
+                const half_t* src = m >= 0 ? p.res + (long long)m * p.ldr + n_base + stage_src<CH>(cpos, q) * 8 : g_zero_page_epi;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(stage + (wave + 4 * i) * 1024), 16, 0, 0);
+            }
+        }
+        __syncthreads();                          // drains the LDS-DMA (vmcnt(0)), then barrier
+    }
+    igemm_epilogue<BM, BN, 1>(p, acc, m_of, n_base + wn * (BN / 2), fq, 0, slab_of, nullptr, nullptr, nullptr, 0,
+                              stage, wm * (BM / 2), wn * (BN / 2));
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int v = tid + 256 * i;
+        if (v < PIECES) {
+            const int q = v / CH, cpos = v - q * CH;
+            const int m = row_of(q);
+            if (m >= 0) *reinterpret_cast<h8*>(p.out + (long long)m * p.ldo + n_base + stage_src<CH>(cpos, q) * 8) =
+                            *reinterpret_cast<const h8*>(stage + v * 16);
         }
     }
 }

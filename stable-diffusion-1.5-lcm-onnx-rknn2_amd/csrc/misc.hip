@@ -676,6 +676,55 @@ extern "C" int lcm_debug_spin(int usec, void* stream) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Measurement only (tools/seam_cost.py): what ONE grid-wide seam costs inside a launch on this chip -- the price a cooperative
+// "whole transformer block in one kernel" would pay per GEMM -> GEMM dependency instead of a kernel boundary.  n_barriers
+// rounds of: every workgroup writes a 128-byte record (plain stores), lane 0 releases (agent scope), arrives on ONE monotonic
+// counter, polls it relaxed with s_sleep -- BOUNDED: after `spin_limit` polls the workgroup gives up, sets the timeout word and
+// every later round falls through, so the grid always drains -- then acquires and every wave re-reads a record of another
+// workgroup.  The grid must be co-resident (<= 256 workgroups of 256 threads: one per CU).  Never used by the product path.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void grid_barrier_probe_kernel(unsigned* counter, unsigned* timeout, float* records, int n_barriers,
+                                                                 unsigned spin_limit, float* sink) {
+    const int wg = blockIdx.x, nwg = gridDim.x;
+    float acc = 0.f;
+    for (int r = 0; r < n_barriers; ++r) {
+        if (threadIdx.x < 32) records[(long long)wg * 32 + threadIdx.x] = (float)(r + wg + threadIdx.x);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned want = (unsigned)(r + 1) * (unsigned)nwg;
+            unsigned spins = 0;
+            while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                if (__hip_atomic_load(timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u || ++spins > spin_limit) {
+                    __hip_atomic_store(timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        acc += records[(long long)((wg + 1 + r) % nwg) * 32 + (threadIdx.x & 31)];
+    }
+    if (sink && acc == -1.f) *sink = acc;
+}
+
+extern "C" int lcm_debug_grid_barrier(int workgroups, int n_barriers, void* state, void* stream) {
+    // state: >= 8 + workgroups * 128 bytes of device memory; words 0 / 1 = counter / timeout (zeroed here, every call)
+    LCM_REQUIRE(workgroups >= 1 && workgroups <= 256 && n_barriers >= 0 && n_barriers <= 4096 && state, "debug_grid_barrier: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(state, 0, 16, s) != hipSuccess) { lcm_set_error("debug_grid_barrier: memset failed"); return LCM_EINVAL; }
+    hipLaunchKernelGGL(grid_barrier_probe_kernel, dim3(workgroups), dim3(256), 0, s, (unsigned*)state, (unsigned*)state + 1,
+                       (float*)((char*)state + 16), n_barriers, 2000000u, (float*)nullptr);
+    LCM_CHECK_LAUNCH("debug_grid_barrier");
+    return LCM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // CLIPTextEmbeddings: out[b*S + s][:] = token_embedding[ids[b*S + s]][:] + position_embedding[s][:]
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void embed_tokens_kernel(const int* __restrict__ ids, const half_t* __restrict__ tok,

@@ -61,6 +61,7 @@ _SIGS = {
     "lcm_graph_destroy": [_vp],
     "lcm_gemm_tile_config": [_i, _i, _i],
     "lcm_debug_spin": [_i, _vp],
+    "lcm_debug_grid_barrier": [_i, _i, _vp, _vp],
     "lcm_axpy_f16": [_vp, _vp, _f, _vp, _i64, _vp],
     "lcm_vae_blend_f32": [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp],
     "lcm_vae_place_tile": [_vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
@@ -79,6 +80,7 @@ _SIGS = {
     "lcm_set_persist_n": [_i],
     "lcm_set_halo_pipe_threshold": [_i],
     "lcm_set_halo_prefetch": [_i],
+    "lcm_set_staged_epilogue": [_i],
     "lcm_set_gn_fused_bytes": [_i64],
     "lcm_plan_set": [_i] * 9,
     "lcm_plan_clear": [],

@@ -551,6 +551,11 @@ def vae_place_tile(tile, th, tw, out_u8, out_f32, H, W, B, oy, ox, ch, cw):
                "lcm_vae_place_tile")
 
 
+def set_staged_epilogue(on):
+    """A/B switch: 1 (default) = the halo conv's plain launches move the residual / result tile through LDS in whole rows."""
+    _lib.check(_lib.load().lcm_set_staged_epilogue(int(on)), "lcm_set_staged_epilogue")
+
+
 def debug_spin(usec):
     _lib.check(_lib.load().lcm_debug_spin(int(usec), _stream()), "lcm_debug_spin")
 

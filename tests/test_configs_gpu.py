@@ -29,14 +29,15 @@ def _golden(case):
     return np.load(p)
 
 
-# The final latents: fp16-operand kernels against the fp32 oracle.  North_star's tolerance is stated on the decoded image; for
-# the latents (values of order 1, up to ~4) the bound is set from measurement: max |delta| 0.6-1.5e-2 over the cases, asserted
-# at 4e-2 (a wrong tile border, a skipped step or a mis-scaled sigma shows up as >= 1e-1).
-LATENT_TOL = 4e-2
+# The final latents: fp16-operand kernels against the fp32 oracle.  North_star's tolerance is stated on the decoded image; the
+# latents of the synthetic weights have a standard deviation of 16-24 (|max| 65-105), so their bound is relative to that scale:
+# max |delta| < 5e-3 x std(oracle latents) -- five fp16 steps at the scale of the data (measured: 1.8e-3 x std at 768^2 / 8 steps,
+# the largest of the guidance-1 cases) -- times the guidance scale under classifier-free guidance (SDXL, g = 5: 1.2e-2 x std).  A wrong tile border, a skipped step or a mis-scaled sigma shows up at >= 5e-2 x std.
+LATENT_REL_TOL = 5e-3
 U8_HALF_STEP = 0.5 / 255.0
 
 
-def _err_vs(out, gold, ref_fn, req=0):
+def _err_vs(out, gold, ref_fn, req=0, guidance=1.0):
     """Per-pixel error of request ``req`` on the decoded [0,1] image, EVERY pixel.  With a fixture: (a) the float image against
     the oracle's full u8 image -- |x - u8/255| + 0.5/255 bounds |x - x_oracle| for every pixel, returned as the error; (b) the
     float image against the fixture's exact fp16 values on the stride-4 grid; (c) the final latents in full.  Live: everything
@@ -50,14 +51,18 @@ def _err_vs(out, gold, ref_fn, req=0):
         assert full.shape == out["rgb"][req].shape
         e = np.abs(_img01(img[0]).transpose(1, 2, 0) - full.astype(np.float32) / 255.0) + U8_HALF_STEP
         u8 = int(np.abs(out["rgb"][req].astype(int) - full.astype(int)).max())
-        lat = np.abs(out["latents"][req].astype(np.float32) - gold["latents"][0].astype(np.float32))
-        print(f"[parity] latents max|d|={lat.max():.4g} mean|d|={lat.mean():.3g}; grid max|d|={eg.max():.4g}; all pixels: u8 max diff {u8}")
-        assert lat.max() < LATENT_TOL, f"final latents: max|d|={lat.max():.4g}"
+        gl = gold["latents"][0].astype(np.float32)
+        lat = np.abs(out["latents"][req].astype(np.float32) - gl)
+        print(f"[parity] latents max|d|={lat.max():.4g} = {lat.max() / gl.std():.3g} x std ({gl.std():.3g}), mean|d|={lat.mean():.3g}; "
+              f"grid max|d|={eg.max():.4g}; all pixels: u8 max diff {u8}")
+        # classifier-free guidance extrapolates: eps = eps_u + g (eps_t - eps_u) carries g times the rounding of its two inputs
+        assert lat.max() < LATENT_REL_TOL * max(1.0, guidance) * gl.std(), f"final latents: max|d|={lat.max():.4g} against std {gl.std():.4g}"
         return e, u8
     ref = ref_fn()
     e = np.abs(_img01(img) - _img01(ref["image"]))
-    lat = np.abs(out["latents"][req].astype(np.float32) - ref["latents"][0].astype(np.float32))
-    assert lat.max() < LATENT_TOL, f"final latents: max|d|={lat.max():.4g}"
+    gl = ref["latents"][0].astype(np.float32)
+    lat = np.abs(out["latents"][req].astype(np.float32) - gl)
+    assert lat.max() < LATENT_REL_TOL * max(1.0, guidance) * gl.std(), f"final latents: max|d|={lat.max():.4g} against std {gl.std():.4g}"
     return e, int(np.abs(out["rgb"][req:req + 1].astype(int) - ref["image_u8"].astype(int)).max())
 
 
@@ -177,7 +182,8 @@ def test_config4_sdxl_1024_parity(sdxl, guidance, steps):
         okw.update(negative_embeds=torch.zeros_like(pe).float(), negative_added=(torch.zeros_like(pooled).float(), tids))
     out = hip.generate(pe, [21], 1024, 1024, steps, guidance, want_float=True, **kw)
     assert out["rgb"].shape == (1, 1024, 1024, 3)
-    e, _ = _err_vs(out, _golden(f"sdxl_1024_g{int(guidance)}_{steps}step"), lambda: ora()(pe.float(), 1024, 1024, steps, guidance, 21, **okw))
+    e, _ = _err_vs(out, _golden(f"sdxl_1024_g{int(guidance)}_{steps}step"), lambda: ora()(pe.float(), 1024, 1024, steps, guidance, 21, **okw),
+                   guidance=guidance)
     print(f"[parity] SDXL 1024x1024 g={guidance} {steps}-step: max|d|={e.max():.4g} mean|d|={e.mean():.3g}")
     assert e.max() < 1e-2
     rep = hip.generate(pe, [21], 1024, 1024, steps, guidance, **kw)             # captured graph == the eager pass

@@ -157,6 +157,21 @@ def test_worker_interface_mirror_and_errors(monkeypatch):
         monkeypatch.setenv("MODEL", "synthetic")
         with pytest.raises(LcmHipError, match="no CPU fallback"):       # product path fails loudly, never falls back
             worker_factory.create_hip_worker(worker_id=0)
+    # CUDA_DTYPE: the reference honours fp16 / bf16 / fp32 and rejects anything else (backends/cuda_worker.py:55-61); this backend
+    # has one arithmetic, so bf16 / fp32 are refused -- not silently run in fp16 -- unless LCM_HIP_DTYPE=fp16 says so
+    monkeypatch.setenv("MODEL", "synthetic")
+    monkeypatch.setenv("CUDA_DTYPE", "fp8")
+    with pytest.raises(RuntimeError, match="Unknown CUDA_DTYPE=fp8"):
+        worker_factory.create_hip_worker(worker_id=0)
+    for dt in ("fp32", "bf16"):
+        monkeypatch.setenv("CUDA_DTYPE", dt)
+        monkeypatch.delenv("LCM_HIP_DTYPE", raising=False)
+        with pytest.raises(RuntimeError, match=f"CUDA_DTYPE={dt} is not available with BACKEND=hip"):
+            worker_factory.create_hip_worker(worker_id=0)
+        if not torch.cuda.is_available():
+            monkeypatch.setenv("LCM_HIP_DTYPE", "fp16")                  # explicit override: construction proceeds (to the GPU check)
+            with pytest.raises(LcmHipError, match="no CPU fallback"):
+                worker_factory.create_hip_worker(worker_id=0)
 
 
 def test_png_encoding_is_deterministic_and_lossless():

@@ -1250,3 +1250,53 @@ def test_fused_mlp_refuses_what_it_cannot_reproduce():
     z = torch.zeros(2560, dtype=torch.float32, device=DEV)
     with pytest.raises(LcmHipError, match="canonical K partition"):
         ops.mlp_geglu(x, w1, z, z, w2, None, x, img_rows=256)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,mode", [(2, 64, 64, 128, 128, "gn"), (1, 40, 24, 128, 128, "plain"), (2, 33, 20, 64, 320, "plain"),
+                                                (1, 16, 16, 320, 640, "gn"), (2, 12, 12, 128, 64, "ups"), (1, 8, 40, 64, 320, "plain160"),
+                                                (2, 16, 24, 128, 320, "plain160")])
+def test_staged_epilogue_is_bit_identical(B, H, W, Cin, Cout, mode):
+    """The halo conv's plain launches move the residual / result tile through an LDS image of the tile in whole rows
+    (tile_epilogue_staged) instead of 8-byte pieces per lane: data movement only -- output and fused GroupNorm statistics must be
+    the same bits, with and without residual, on ragged images (tiles hanging over the border), 64 / 128 / 160-wide tiles, the
+    GroupNorm-fused staging and the phase-decomposed upsample."""
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B * H * W, Cin, generator=g).half().to(DEV)
+    ups = 2 if mode == "ups" else 0
+    Ho, Wo = (2 * H, 2 * W) if ups else (H, W)
+    wt = torch.randn(Cout, Cin, 3, 3, generator=g) * (9 * Cin) ** -0.5
+    from sdlcm_amd.packing import pack_conv3x3, pack_conv3x3_up2
+    w = (pack_conv3x3_up2(wt.half()) if ups else pack_conv3x3(wt.half())).to(DEV)
+    bias = torch.randn(Cout, generator=g).half().to(DEV)
+    res = torch.randn(B * Ho * Wo, Cout, generator=g).half().to(DEV)
+    sc = (torch.rand(B, Cin, generator=g) + 0.5).to(DEV)
+    sh = (torch.randn(B, Cin, generator=g) * 0.1).to(DEV)
+    outs = {}
+    ops.set_halo_pipe_threshold(0)          # small grids too take the single-buffer kernel (the one that has the staged form)
+    if mode == "plain160":                  # the 160-wide tile (20 chunks per pixel row: the rotation is not a power of two)
+        ops.plan_set(2, B * H * W, Cout, 9 * Cin, W << 1, 128 if H * W >= 256 and W >= 16 else 64, 160, 1, 1)
+        mode = "plain"
+    try:
+        for staged in (0, 1):
+            ops.set_staged_epilogue(staged)
+            for with_res in (False, True):
+                o = torch.full((B * Ho * Wo + 64, Cout), 7.0, dtype=torch.float16, device=DEV)      # guard rows behind the output
+                st = ops.Stats(torch.zeros(ops.stats_floats(B * Ho * Wo, Cout, Ho * Wo), dtype=torch.float32, device=DEV))
+                kw = dict(bias=bias, stats=st, res=res if with_res else None)
+                if mode == "gn":
+                    ops.conv3x3_gn(x, w, o[:B * Ho * Wo], B, H, W, Cin, Cout, gn_scale=sc, gn_shift=sh, silu=True, **kw)
+                else:
+                    ops.conv3x3(x, w, o[:B * Ho * Wo], B, H, W, Cin, Cout, ups=ups, **kw)
+                torch.cuda.synchronize()
+                assert bool((o[B * Ho * Wo:] == 7.0).all()), "wrote past the output"
+                outs[(staged, with_res)] = (o[:B * Ho * Wo].clone(), st.buf.clone(), st.P)
+    finally:
+        ops.set_staged_epilogue(1)
+        ops.set_halo_pipe_threshold(768)
+        ops.plan_reset()
+    for with_res in (False, True):
+        a, b = outs[(0, with_res)], outs[(1, with_res)]
+        assert a[2] == b[2]
+        assert torch.equal(a[0], b[0]), f"staged epilogue changes the output (residual {with_res}): max |d| {(a[0].float() - b[0].float()).abs().max().item():.3g}"
+        assert torch.equal(a[1], b[1]), "staged epilogue changes the fused statistics"
+    assert not torch.equal(outs[(1, False)][0], outs[(1, True)][0])

@@ -248,3 +248,30 @@ def test_other_lanes_serve_when_lane0_is_gone():
         assert mb.submit("k", 1).result(5)[1] == 1
     finally:
         mb.close()
+
+
+def test_factory_binds_the_named_queue_to_every_worker_it_creates(monkeypatch):
+    """A pool built by hand names its queue once (worker_factory.set_pool_queue); workers created later -- the pool re-creates
+    its worker on every mode switch -- are bound by the factory."""
+    import queue
+    from sdlcm_amd.backends import hip_worker, worker_factory
+    made = []
+
+    class W:
+        def __init__(self, worker_id):
+            self.q = None
+            made.append(self)
+
+        def bind_queue(self, q):
+            self.q = q
+    monkeypatch.setattr(hip_worker, "HipLcmWorker", W)
+    monkeypatch.setenv("MODEL", "synthetic")
+    q = queue.Queue()
+    first = worker_factory.create_hip_worker(worker_id=0)
+    assert first.q is None
+    worker_factory.set_pool_queue(q, first)
+    try:
+        assert first.q is q and worker_factory.create_hip_worker(worker_id=0).q is q
+    finally:
+        worker_factory.set_pool_queue(None)
+    assert worker_factory.create_hip_worker(worker_id=0).q is None

@@ -40,6 +40,9 @@ def case(B, H, Cin, Cout, xform=True, iters=6):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1:
+        ops.set_staged_epilogue(int(sys.argv[1]))
+        print(f"staged epilogue: {sys.argv[1]}")
     case(8, 512, 128, 128)
     case(8, 256, 256, 256)
     case(8, 512, 128, 128, xform=False)
