@@ -187,8 +187,9 @@ int lcm_set_halo_pipe_threshold(int wgs);
 /* GroupNorm-fused convolution (lcm_conv3x3_gn_f16 with scale / shift): 1 = the raw halo of the next 64-channel chunk
  * is fetched into registers under the taps of the current one (measured slower: 202 VGPRs, two workgroups per CU instead of three), 0 (default) = fetched where it is consumed.  Bit-neutral. */
 int lcm_set_halo_prefetch(int on);
-/* 1 (default): the LDS-halo convolution's plain (unsplit) launches fetch the residual tile by LDS-DMA and store the result tile
- * in whole rows through an LDS image of the tile; 0: 8-byte pieces per lane.  Bit-neutral. */
+/* bit 0 (default on): the LDS-halo convolution's plain (unsplit) launches with a residual fetch the residual tile by LDS-DMA and
+ * store the result tile in whole rows through an LDS image of the tile; bit 1 (default off: measured neutral): plain GEMMs with a
+ * residual too; 0: 8-byte pieces per lane everywhere.  Bit-neutral. */
 int lcm_set_staged_epilogue(int on);
 /* 1 (default): stride-1 3x3 convolutions use the LDS-halo kernel; 0: the row-gather implicit GEMM everywhere */
 int lcm_set_conv_impl(int impl);

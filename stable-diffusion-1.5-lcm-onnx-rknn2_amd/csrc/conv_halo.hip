@@ -620,7 +620,8 @@ int lcm_canonical_splits_halo(int m_img, int N, int K, int IH, int IW, int W, in
 
 static int g_staged_epi = 1;     // 1: plain (unsplit) launches move residual / result through an LDS image of the tile in whole
                                  // rows; 0: per-lane 8-byte pieces.  Bit-identical (A/B switch)
-extern "C" int lcm_set_staged_epilogue(int on) { g_staged_epi = on ? 1 : 0; return LCM_OK; }
+extern int g_staged_epi_gemm;
+extern "C" int lcm_set_staged_epilogue(int on) { g_staged_epi = (on & 1) ? 1 : 0; g_staged_epi_gemm = (on & 2) ? 1 : 0; return LCM_OK; }
 
 // returns 0 when launched, 1 when the shape is not handled here, < 0 on error
 int lcm_conv_halo_launch(HaloParams& hp, int B, hipStream_t s, int* slabs_per_image) {

@@ -191,8 +191,11 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int MODE, int S, int LN = 0, int SEG = 0>
+// EPI = 1 (plain launches with a residual: MODE 0, no LayerNorm fold, no segments, one n-tile per workgroup): the residual tile
+// arrives by LDS-DMA and the result leaves in whole rows through an LDS image of the tile laid over the ring (tile_epilogue_staged)
+template <int BM, int BN, int MODE, int S, int LN = 0, int SEG = 0, int EPI = 0>
 __global__ __launch_bounds__(256, S == 1 ? (BM + BN < 256 ? 4 : 3) : 2) void igemm2_kernel(IgemmParams p) {
+    static_assert(!EPI || (MODE == 0 && !LN && !SEG && S * (BM + BN) * 128 >= BM * BN * 2), "staged epilogue: plain GEMM whose ring holds the tile");
     // SEG = 1: segmented accumulation.  The launch's canonical K partition has p.seg_parts parts but this (batched) launch
     // fills the chip without splitting: one workgroup walks all of K, keeps the running part in `acc` and adds the finished
     // parts into `tot` in part order -- the additions the split-K reduce makes, in registers, with no fp32 slabs in HBM.
@@ -402,6 +405,9 @@ __global__ __launch_bounds__(256, S == 1 ? (BM + BN < 256 ? 4 : 3) : 2) void ige
             if constexpr (ln) {
                 ln_finish<TM>(ln_s, ln_q, p.K, p.ln_eps);
                 igemm_epilogue<BM, BN>(p, acc, m_of, (nt0 + ni_cur) * BN + wn * (BN / 2), fq, z, slab_of, ln_s, ln_q, ln_lds, nt0 * BN);
+            } else if constexpr (EPI != 0) {       // (the launcher gives such a launch one n-tile per workgroup: the ring is dead here)
+                tile_epilogue_staged<BM, BN>(p, acc, m_of, (nt0 + ni_cur) * BN, wm, wn, fq, slab_of, smem,
+                                             [&](int q) { return m_base + q < p.M ? m_base + q : -1; });
             } else {
                 igemm_epilogue<BM, BN>(p, acc, m_of, (nt0 + ni_cur) * BN + wn * (BN / 2), fq, z, slab_of);
             }
@@ -708,9 +714,28 @@ extern "C" int lcm_gemm_tile_config(int M, int N, int batch) {
     return t.bm * 1000 + t.bn;
 }
 
+int g_staged_epi_gemm = 0;       // lcm_set_staged_epilogue bit 1: plain GEMMs with a residual take the staged epilogue too.  Off: measured
+                                 // neutral to -3 % on the transformer shapes (tools/gemm_epi_ab.py: 22.3 / 22.3, 19.8 / 20.5, 48.2 / 49.2 us) --
+                                 // their epilogue is not what bounds them; the 3x3 convolutions' is (conv_halo.hip)
+
 template <int BM, int BN, int MODE, int S, int LN = 0, int SEG = 0>
 static int launch_v2(IgemmParams& p, dim3 grid, hipStream_t s) {
     constexpr int smem = S * (BM + BN) * 128 + (LN ? 2 * BN * 4 : 0);       // LN: + this n-tile's ln_g | ln_c
+    // the staged epilogue: a plain launch with a residual tile to fetch, the tile image fits the ring, strided z-batches excluded
+    constexpr bool can_stage = MODE == 0 && !LN && !SEG && S * (BM + BN) * 128 >= BM * BN * 2;
+    if constexpr (can_stage) if (g_staged_epi_gemm && p.res && p.splits == 1 && p.n_iters == 1 && p.epi == 0 && grid.z == 1) {
+        static LcmDevOnce attr_once_e;
+        if (auto once_guard = attr_once_e.first()) {
+            once_guard.check(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<BM, BN, MODE, S, LN, SEG, 1>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        }
+        char nm[64];
+        snprintf(nm, sizeof(nm), "igemm2_kernel<%d, %d, %d, %d, %d, %d, 1>", BM, BN, MODE, S, LN, SEG);
+        lcm_prof_start(nm, s);
+        hipLaunchKernelGGL((igemm2_kernel<BM, BN, MODE, S, LN, SEG, 1>), grid, dim3(256), smem, s, p);
+        lcm_prof_stop(s);
+        return 0;
+    }
     static LcmDevOnce attr_once;
     if (auto once_guard = attr_once.first()) {
         once_guard.check(hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm2_kernel<BM, BN, MODE, S, LN, SEG>),

@@ -1300,3 +1300,33 @@ def test_staged_epilogue_is_bit_identical(B, H, W, Cin, Cout, mode):
         assert torch.equal(a[0], b[0]), f"staged epilogue changes the output (residual {with_res}): max |d| {(a[0].float() - b[0].float()).abs().max().item():.3g}"
         assert torch.equal(a[1], b[1]), "staged epilogue changes the fused statistics"
     assert not torch.equal(outs[(1, False)][0], outs[(1, True)][0])
+
+
+@pytest.mark.parametrize("M,N,K,plan", [(4096, 320, 320, (128, 160, 2)), (1000, 640, 640, (64, 160, 3)), (300, 320, 1280, (64, 64, 4)),
+                                        (4096, 1280, 1280, (128, 128, 2)), (520, 320, 320, (128, 64, 2))])
+def test_staged_epilogue_of_plain_gemms_is_bit_identical(M, N, K, plan):
+    """Plain GEMMs with a residual (attn.to_out, ff.net.2, proj_out) take the staged epilogue too (igemm2_kernel<..., EPI = 1>):
+    same output and same fused statistics as the per-lane form, ragged last tile, in-place residual (out aliases res)."""
+    a = rnd(M, K, seed=1).to(DEV)
+    w = rnd(N, K, seed=2, scale=K ** -0.5).to(DEV)
+    b = rnd(N, seed=3).to(DEV)
+    r = rnd(M, N, seed=4).to(DEV)
+    outs = []
+    try:
+        ops.plan_set(0, M, N, K, 1, plan[0], plan[1], 1, plan[2])
+        for staged in (0, 3):                 # bit 1 = the GEMM side of the switch (off by default: measured neutral)
+            ops.set_staged_epilogue(staged)
+            h = torch.full((M + 16, N), 7.0, dtype=torch.float16, device=DEV)
+            h[:M].copy_(r)
+            st = ops.Stats(torch.zeros(ops.stats_floats(M, N, M), dtype=torch.float32, device=DEV)) if M % 32 == 0 else None
+            ops.gemm(a, w, h[:M], bias=b, res=h[:M], stats=st, img_rows=M)          # in place, as the transformer blocks call it
+            torch.cuda.synchronize()
+            assert bool((h[M:] == 7.0).all())
+            outs.append((h[:M].clone(), st.buf.clone() if st is not None else None, st.P if st is not None else 0))
+    finally:
+        ops.set_staged_epilogue(1)
+        ops.plan_reset()
+    assert torch.equal(outs[0][0], outs[1][0]) and outs[0][2] == outs[1][2]
+    if outs[0][1] is not None:
+        assert torch.equal(outs[0][1], outs[1][1])
+    close(outs[1][0], F.linear(a.float().cpu(), w.float().cpu(), b.float().cpu()) + r.float().cpu(), what="gemm + residual (staged)")
