@@ -269,7 +269,7 @@ __device__ __forceinline__ void halo_wait_vmcnt() {
 // ds_reads of tap i+1 run under the MFMAs of tap i and there is one barrier per row.
 // SEG = 1: segmented accumulation (see igemm2_kernel): the canonical K partition (over 64-channel chunks) of a batched launch
 // is kept in registers -- finished parts are added into `tot` in part order -- instead of fp32 slabs + a reduce launch.
-template <int TH, int TW, int BN, int WS, int PH, int TPS, int SEG = 0>
+template <int TH, int TW, int BN, int WS, int PH, int TPS, int SEG = 0, int EPI = 0>
 __global__ __launch_bounds__(256, 2) void conv_halo_pipe_kernel(HaloParams hp) {
     constexpr int NT = PH ? 4 : 9;
     constexpr int G = NT / TPS;            // K-steps per 64-channel chunk
@@ -479,8 +479,18 @@ __global__ __launch_bounds__(256, 2) void conv_halo_pipe_kernel(HaloParams hp) {
     }
     int slab_of[BM / 64];
     halo_slabs<TH, TW, PH>(slab_of, wm, bimg, y0, x0, IH, IW, phase);
-    if constexpr (SEG) igemm_epilogue<BM, BN>(p, tot, m_of, n_base + wn * (BN / 2), fq, 0, slab_of);
-    else igemm_epilogue<BM, BN>(p, acc, m_of, n_base + wn * (BN / 2), fq, 0, slab_of);
+    if constexpr (EPI != 0) {       // staged: the tile image lies over the (dead) halo buffers and weight ring
+        static_assert(2 * XBYTES + WS * SBYTES >= BM * BN * 2, "staged epilogue: the ring holds the tile");
+        auto row_of = [&](int q) {
+            const int y = y0 + q / TW, x = x0 + q % TW;
+            return (y < IH && x < IW) ? (PH ? (bimg * hp.H + 2 * y + py) * hp.W + 2 * x + px : (bimg * hp.H + y) * hp.W + x) : -1;
+        };
+        if constexpr (SEG) tile_epilogue_staged<BM, BN>(p, tot, m_of, n_base, wm, wn, fq, slab_of, smem, row_of);
+        else tile_epilogue_staged<BM, BN>(p, acc, m_of, n_base, wm, wn, fq, slab_of, smem, row_of);
+    } else {
+        if constexpr (SEG) igemm_epilogue<BM, BN>(p, tot, m_of, n_base + wn * (BN / 2), fq, 0, slab_of);
+        else igemm_epilogue<BM, BN>(p, acc, m_of, n_base + wn * (BN / 2), fq, 0, slab_of);
+    }
 }
 
 // split-K combine kernel lives in igemm.hip
@@ -516,6 +526,18 @@ static void launch_halo(HaloParams& hp, hipStream_t s, int force) {     // force
                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         }
         char nm[80];
+        if (hp.staged_epi && hp.g.res && hp.g.splits == 1) {       // segmented launch with a residual: staged epilogue
+            static LcmDevOnce attr_once_e;
+            if (auto once_guard = attr_once_e.first()) {
+                once_guard.check(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_pipe_kernel<TH, TW, BN, WS, PH, TPS, 1, 1>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            }
+            snprintf(nm, sizeof(nm), "conv_halo_pipe_kernel<%d, %d, %d, %d, %d, %d, 1, 1>", TH, TW, BN, WS, PH, TPS);
+            lcm_prof_start(nm, s);
+            hipLaunchKernelGGL((conv_halo_pipe_kernel<TH, TW, BN, WS, PH, TPS, 1, 1>), grid, dim3(256), smem, s, hp);
+            lcm_prof_stop(s);
+            return;
+        }
         snprintf(nm, sizeof(nm), "conv_halo_pipe_kernel<%d, %d, %d, %d, %d, %d, 1>", TH, TW, BN, WS, PH, TPS);
         lcm_prof_start(nm, s);
         hipLaunchKernelGGL((conv_halo_pipe_kernel<TH, TW, BN, WS, PH, TPS, 1>), grid, dim3(256), smem, s, hp);

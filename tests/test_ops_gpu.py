@@ -1254,7 +1254,7 @@ def test_fused_mlp_refuses_what_it_cannot_reproduce():
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,mode", [(2, 64, 64, 128, 128, "gn"), (1, 40, 24, 128, 128, "plain"), (2, 33, 20, 64, 320, "plain"),
                                                 (1, 16, 16, 320, 640, "gn"), (2, 12, 12, 128, 64, "ups"), (1, 8, 40, 64, 320, "plain160"),
-                                                (2, 16, 24, 128, 320, "plain160")])
+                                                (2, 16, 24, 128, 320, "plain160"), (2, 16, 16, 1280, 1280, "seg"), (2, 32, 32, 640, 640, "seg")])
 def test_staged_epilogue_is_bit_identical(B, H, W, Cin, Cout, mode):
     """The halo conv's plain launches move the residual / result tile through an LDS image of the tile in whole rows
     (tile_epilogue_staged) instead of 8-byte pieces per lane: data movement only -- output and fused GroupNorm statistics must be
@@ -1276,6 +1276,10 @@ def test_staged_epilogue_is_bit_identical(B, H, W, Cin, Cout, mode):
     if mode == "plain160":                  # the 160-wide tile (20 chunks per pixel row: the rotation is not a power of two)
         ops.plan_set(2, B * H * W, Cout, 9 * Cin, W << 1, 128 if H * W >= 256 and W >= 16 else 64, 160, 1, 1)
         mode = "plain"
+    if mode == "seg":                       # segmented accumulation (the batched form of a layer whose K partition has parts): pipe kernel
+        assert ops.canonical_splits(2, H * W, Cout, 9 * Cin, W << 1, 0) > 1
+        ops.set_seg_mode(1)
+        mode = "plain"
     try:
         for staged in (0, 1):
             ops.set_staged_epilogue(staged)
@@ -1293,6 +1297,7 @@ def test_staged_epilogue_is_bit_identical(B, H, W, Cin, Cout, mode):
     finally:
         ops.set_staged_epilogue(1)
         ops.set_halo_pipe_threshold(768)
+        ops.set_seg_mode(0)
         ops.plan_reset()
     for with_res in (False, True):
         a, b = outs[(0, with_res)], outs[(1, with_res)]

@@ -48,3 +48,5 @@ if __name__ == "__main__":
     case(8, 512, 128, 128, xform=False)
     case(8, 128, 512, 512, xform=False)
     case(8, 64, 320, 320, xform=False)
+    case(8, 32, 640, 640, xform=False)          # segmented accumulation: conv_halo_pipe_kernel<8,16,160,3,0,1,1[,1]>
+    case(8, 16, 1280, 1280, xform=False)

@@ -11,12 +11,13 @@ ops.set_kernel_variant(variant)
 x = torch.randn(B * H * H, Cin, device="cuda", dtype=torch.float16)
 w = torch.randn(Cout, 9 * Cin, device="cuda", dtype=torch.float16)
 o = torch.empty(B * H * H, Cout, device="cuda", dtype=torch.float16)
-gn = len(sys.argv) > 6 and sys.argv[6] == "gn"       # GroupNorm-fused form (scale / shift tables applied while staging the halo)
+gn = len(sys.argv) > 6 and "gn" in sys.argv[6:]      # GroupNorm-fused form (scale / shift tables applied while staging the halo)
+res = torch.randn(B * H * H, Cout, device="cuda", dtype=torch.float16) if "res" in sys.argv[6:] else None      # + residual (conv2 of a resnet)
 if gn:
     sc, sh = torch.rand(B, Cin, device="cuda") + 0.5, torch.randn(B, Cin, device="cuda") * 0.1
 for _ in range(5):
     if gn:
-        ops.conv3x3_gn(x, w, o, B, H, H, Cin, Cout, gn_scale=sc, gn_shift=sh, silu=True)
+        ops.conv3x3_gn(x, w, o, B, H, H, Cin, Cout, gn_scale=sc, gn_shift=sh, silu=True, res=res)
     else:
-        ops.conv3x3(x, w, o, B, H, H, Cin, Cout)
+        ops.conv3x3(x, w, o, B, H, H, Cin, Cout, res=res)
 torch.cuda.synchronize()

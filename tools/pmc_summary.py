@@ -20,6 +20,7 @@ TAGS = {"gemm64_b1": "gemm M4096 N320 K320 (batch-1 transformer GEMM, 64x64 tile
         "attn2_b1": "self-attention 1 image x 8 heads, S = 4096, d = 40 (UNet level 0, batch 1; key-split form, 8 waves)",
         "attn2_b8_unsplit": "the same launch with lcm_set_attention_ksplit(0)",
         "attn2_b1_unsplit": "the same launch with lcm_set_attention_ksplit(0)",
+        "convgnres_b8": "the same convolution with a residual (conv2 of a ResnetBlock2D): staged epilogue",
         "mlp_b8": "fused FeedForward (norm3 -> ff.net.0 -> GEGLU -> ff.net.2 -> + h), 32768 rows x C 320 (UNet level 0, batch 8)",
         "ff1_b8": "LayerNorm-folded GEGLU projection M32768 N2560 K320 (the first of the two launches the fused kernel replaces)",
         "ff2_b8": "ff.net.2 + residual M32768 N320 K1280 (the second of the two launches)",
@@ -45,7 +46,9 @@ for tag, what in TAGS.items():
     busy = vals.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / 1024.0
     gui = vals.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
     hbm = (2.0 * vals.get("FETCH_SIZE", 0.0) + vals.get("WRITE_SIZE", 0.0)) * 1024.0
-    out[kern] = dict(what=what, source=f"profiles/{ROUND}_pmc_{tag}.txt", sources=kernel_sources(kern), source_sha256=sources_sha256(kernel_sources(kern)), avg_us=round(avg_us, 2) if avg_us else None,
+    if kern in out:
+        kern = f"{kern} [{tag}]"          # a second shape of the same instantiation keeps its own entry
+    out[kern] = dict(what=what, source=f"profiles/{ROUND}_pmc_{tag}.txt", sources=kernel_sources(kern.split(' [')[0]), source_sha256=sources_sha256(kernel_sources(kern.split(' [')[0])), avg_us=round(avg_us, 2) if avg_us else None,
                      mfma_busy_cycles_per_simd=round(busy), kernel_cycles=round(gui),
                      mfma_busy_frac=round(busy / gui, 4) if gui else None,
                      mfma_busy_frac_at_2p1ghz=round(busy / (avg_us * 2100.0), 4) if avg_us else None,
