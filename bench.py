@@ -163,7 +163,7 @@ def _pmc_counters(kernel_name):
 
 
 def _pmc_traffic(kernel_name, batch):
-    """HBM-side bytes per launch of `kernel_name`, from the committed PMC passes (profiles/r03_traffic.json: rocprofv3 --pmc
+    """HBM-side bytes per launch of `kernel_name`, from the committed PMC passes (profiles/r04_traffic.json: rocprofv3 --pmc
     FETCH_SIZE and WRITE_SIZE in separate runs over one eager pass of this workload, tools/pmc_pass.sh; counters cannot be
     read from inside bench.py).  FETCH_SIZE x2 is the gfx950 correction of MI355X_MICROARCH.md's HBM section.  When the
     dominant kernel / batch is not in the file the value is None AND the reason is reported (`traffic_source`) and printed
@@ -171,7 +171,14 @@ def _pmc_traffic(kernel_name, batch):
     import json
     try:
         with open(TRAFFIC_FILE) as f:
-            tab = json.load(f)["batch"].get(str(batch), {})
+            doc = json.load(f)
+        tab = doc["batch"].get(str(batch), {})
+        from tools.check_profiles_fresh import sources_sha256
+        if not doc.get("csrc_sha256") or sources_sha256(doc.get("csrc_files", [])) != doc["csrc_sha256"]:
+            msg = (f"{os.path.relpath(TRAFFIC_FILE, ROOT)} was taken on other kernel sources than this tree's (csrc hash differs): "
+                   f"traffic not reported; re-run tools/pmc_traffic.sh")
+            print("[bench] WARNING: " + msg, file=sys.stderr)
+            return None, msg
     except Exception as e:
         msg = f"{os.path.relpath(TRAFFIC_FILE, ROOT)} unreadable ({e!r}): traffic not reported"
         print("[bench] WARNING: " + msg, file=sys.stderr)

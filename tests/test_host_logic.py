@@ -655,8 +655,12 @@ def test_bench_traffic_lookup_reads_committed_pmc_table(tmp_path, capsys):
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
+    from tools.check_profiles_fresh import CSRC, sources_sha256
+    files = [os.path.join(CSRC, "common.h")]
     tabf = tmp_path / "traffic.json"
-    tabf.write_text(json.dumps({"batch": {"1": {"void k<1>(P)": {"FETCH_SIZE": 100.0, "WRITE_SIZE": 50.0, "n_FETCH_SIZE": 7}}}}))
+    doc = {"batch": {"1": {"void k<1>(P)": {"FETCH_SIZE": 100.0, "WRITE_SIZE": 50.0, "n_FETCH_SIZE": 7}}},
+           "csrc_files": files, "csrc_sha256": sources_sha256(files)}
+    tabf.write_text(json.dumps(doc))
     bench.TRAFFIC_FILE = str(tabf)
     t, src = bench._pmc_traffic("void k<1>(P)", 1)
     assert t == int((2 * 100.0 + 50.0) * 1024) and "x2" in src
@@ -667,6 +671,38 @@ def test_bench_traffic_lookup_reads_committed_pmc_table(tmp_path, capsys):
     bench.TRAFFIC_FILE = str(tmp_path / "missing.json")
     t, src = bench._pmc_traffic("void k<1>(P)", 1)
     assert t is None and "unreadable" in src
+    # a table taken on other kernel sources reports nothing
+    stale = tmp_path / "stale.json"
+    stale.write_text(json.dumps(dict(doc, csrc_sha256="0" * 64)))
+    bench.TRAFFIC_FILE = str(stale)
+    t, src = bench._pmc_traffic("void k<1>(P)", 1)
+    assert t is None and "other kernel sources" in src
+    # counters: unique match required, stale entries nulled
+    summ = tmp_path / "summary.json"
+    ent = dict(what="w", source="s", sources=files, source_sha256=sources_sha256(files), avg_us=100.0, mfma_busy_frac=0.4,
+               mfma_busy_frac_at_2p1ghz=0.3, effective_clock_ghz=1.9, hbm_gbs=1000.0)
+    summ.write_text(json.dumps({"attn2_kernel<40, 8, 1>": ent, "attn2_kernel<40, 8, 2>": ent, "k<1, 2>": dict(ent, source_sha256="0" * 64)}))
+    bench.PMC_SUMMARY_FILE = str(summ)
+    assert bench._pmc_counters("attn2_kernel<40, 8, 2>")["mfma_busy_frac"] == 0.4
+    amb = bench._pmc_counters("attn2_kernel<40, 8")
+    assert amb["mfma_busy_frac"] is None and "matches 2 entries" in amb["pmc_source"]
+    st = bench._pmc_counters("k<1, 2>")
+    assert st["mfma_busy_frac"] is None and "stale" in st["pmc_source"]
+
+
+def test_committed_counter_evidence_was_taken_on_the_kernels_in_the_tree():
+    """PMC evidence went stale when a kernel changed after its counters were collected.  Every entry of this round's
+    profiles/r04_pmc_summary.json and the traffic table record the sha256 of the kernel sources they were taken on
+    (tools/pmc_summary.py, tools/pmc_traffic.py); editing a kernel without re-collecting (tools/pmc_round4.sh, tools/pmc_traffic.sh)
+    fails here."""
+    from tools.check_profiles_fresh import ROOT as R, stale_entries
+    p = os.path.join(R, "profiles", "r04_pmc_summary.json")
+    assert os.path.exists(p), "profiles/r04_pmc_summary.json missing"
+    bad = stale_entries(p)
+    assert not bad, f"stale PMC entries (re-run tools/pmc_round4.sh + tools/pmc_summary.py r04): {bad}"
+    import subprocess, sys
+    r = subprocess.run([sys.executable, os.path.join(R, "tools", "check_profiles_fresh.py"), "r04"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout
 
 
 def test_stream_workspace_entries_are_owned_by_their_pointer():

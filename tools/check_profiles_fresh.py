@@ -66,6 +66,11 @@ def main():
         print(f"{p}: missing")
         return 1
     bad = stale_entries(p)
+    t = os.path.join(ROOT, "profiles", f"{rnd}_traffic.json")
+    if os.path.exists(t):
+        doc = json.load(open(t))
+        if not doc.get("csrc_sha256") or sources_sha256(doc.get("csrc_files", [])) != doc["csrc_sha256"]:
+            bad[os.path.relpath(t, ROOT)] = "taken on other kernel sources than this tree's"
     for k, why in bad.items():
         print(f"STALE {k}: {why}")
     if not bad:

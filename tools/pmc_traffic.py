@@ -4,7 +4,9 @@
   pmc_traffic.py out.json  B:COUNTER:dir  [B:COUNTER:dir ...]
 
 Kernel names are normalised to the instantiation names the library reports ("igemm2_kernel<64, 64, 0, 4>")."""
-import collections, csv, glob, json, re, sys
+import collections, csv, glob, json, os, re, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tools.check_profiles_fresh import CSRC, ROOT, sources_sha256  # noqa: E402
 
 
 def norm(name):
@@ -32,5 +34,8 @@ for spec in sys.argv[2:]:
         e["n_" + counter] = n
 for B in out["batch"]:
     out["batch"][B] = {k: v for k, v in out["batch"][B].items() if "FETCH_SIZE" in v and "WRITE_SIZE" in v}
+# the table describes the kernels of THIS tree: bench.py reports no traffic from a table taken on other sources
+out["csrc_files"] = sorted(os.path.join(CSRC, f) for f in os.listdir(os.path.join(ROOT, CSRC)) if f.endswith((".hip", ".h", ".cpp")))
+out["csrc_sha256"] = sources_sha256(out["csrc_files"])
 json.dump(out, open(sys.argv[1], "w"), indent=1)
 print({B: len(t) for B, t in out["batch"].items()})

@@ -1,5 +1,5 @@
 #!/bin/bash
-# FETCH_SIZE and WRITE_SIZE in SEPARATE rocprofv3 --pmc runs over one eager pass (batch 1 and batch 8) -> gpurun_out/${TRAFFIC_OUT:-r03_traffic.json}
+# FETCH_SIZE and WRITE_SIZE in SEPARATE rocprofv3 --pmc runs over one eager pass (batch 1 and batch 8) -> gpurun_out/${TRAFFIC_OUT:-r04_traffic.json}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 specs=""
 for B in 1 8; do
@@ -12,6 +12,6 @@ for B in 1 8; do
     specs="$specs $B:$c:$d"
   done
 done
-python tools/pmc_traffic.py gpurun_out/${TRAFFIC_OUT:-r03_traffic.json} $specs
-for B in 1 8; do for c in FETCH_SIZE WRITE_SIZE; do python tools/pmc_avg.py gpurun_out/pmc_${B}_$c $c > gpurun_out/r03_pmc_pass_b${B}_$c.txt; rm -rf gpurun_out/pmc_${B}_$c; done; done
-ls -la gpurun_out/${TRAFFIC_OUT:-r03_traffic.json}
+python tools/pmc_traffic.py gpurun_out/${TRAFFIC_OUT:-r04_traffic.json} $specs
+for B in 1 8; do for c in FETCH_SIZE WRITE_SIZE; do python tools/pmc_avg.py gpurun_out/pmc_${B}_$c $c > gpurun_out/r04_pmc_pass_b${B}_$c.txt; rm -rf gpurun_out/pmc_${B}_$c; done; done
+ls -la gpurun_out/${TRAFFIC_OUT:-r04_traffic.json}
