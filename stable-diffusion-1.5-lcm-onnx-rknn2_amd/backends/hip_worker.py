@@ -574,16 +574,17 @@ class HipLcmWorker:
 
     def _gather_wait(self, q, want):
         """Closed-loop callers come back together: the clients of the previous call's batch get their results within a few
-        milliseconds of each other and re-submit.  If that call drained k jobs, give up to LCM_DRAIN_WINDOW_MS (default 4;
-        a batched pass takes 35-125 ms) for about as many to arrive before taking the batch -- otherwise the first arrival runs
-        alone and the rest wait a whole pass for a small batch (measured: mean batch 4.0 -> see DESIGN section 6).  A lone
+        milliseconds of each other and re-submit.  If that call drained k jobs, give about as many time to arrive before taking
+        the batch -- otherwise the first arrival runs alone and the rest wait a whole pass for a small batch.  The window is a
+        tenth of what the previous call took (a batched pass takes 35-125 ms), at most LCM_DRAIN_WINDOW_MS (default 12); a lone
         caller (k == 0) never waits."""
         import time as _t
         k = getattr(self, "_last_drained", 0)
         if k <= 0:
             return
-        win = float(os.environ.get("LCM_DRAIN_WINDOW_MS", "4") or 0) * 1e-3
-        if win <= 0:
+        cap = float(os.environ.get("LCM_DRAIN_WINDOW_MS", "12") or 0) * 1e-3
+        win = min(cap, max(0.002, 0.1 * getattr(self, "_last_call_s", 0.0)))
+        if cap <= 0:
             return
         deadline = _t.perf_counter() + win
         while q.qsize() < want(k) and _t.perf_counter() < deadline:
@@ -597,7 +598,9 @@ class HipLcmWorker:
             return encode_png(rgb), seed
         b = eng.batcher
         limit = b.max_batch * max(1, b.lanes) - 1
+        import time as _t
         self._gather_wait(q, lambda k: min(k, limit))
+        t_call = _t.perf_counter()
         if q.empty():
             self._last_drained = 0
             (rgb, _), seed = self._submit(job)
@@ -633,10 +636,14 @@ class HipLcmWorker:
             rgb, _ = futs[0].result()
             return encode_png(rgb), items[0][1]
         finally:
-            # return to the pool's loop only when every pass this call started has left the GPU (a mode switch may be next
-            # in the queue); the drained jobs' PNGs may still be deflating on the finisher threads -- no GPU state involved
+            # return to the pool's loop only when every pass this call started has left the GPU (a mode switch may be next in
+            # the queue); the drained jobs' PNGs may still be deflating on the finisher threads -- no GPU state involved.
+            # (Returning as soon as the call's own job is done, to keep the second lane fed, was measured at 8 / 16 / 24
+            # closed-loop clients: 79 / 100 / 99 images/s against 86 / 98 / 102 -- the callers fall out of step and the batches
+            # shrink; not kept.)
             for ev in pending:
                 ev.wait()
+            self._last_call_s = _t.perf_counter() - t_call
 
     def run_job_with_latents(self, job) -> Tuple[bytes, int, bytes]:
         # The reference re-runs the whole pipeline for the latents (cuda_worker.py:255-283); the sampler is

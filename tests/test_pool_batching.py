@@ -275,3 +275,34 @@ def test_factory_binds_the_named_queue_to_every_worker_it_creates(monkeypatch):
     finally:
         worker_factory.set_pool_queue(None)
     assert worker_factory.create_hip_worker(worker_id=0).q is None
+
+
+def test_run_job_returns_only_when_every_pass_it_started_has_left_the_gpu():
+    """Whatever is next in the queue -- a mode switch or another generation job -- the pool's loop gets control back only when all
+    passes of the call are done: nothing queued behind a barrier starts before the work queued in front of it is finished."""
+    gate = threading.Event()
+
+    def run_pass(key, items):
+        if any(it[0].prompt == "p15" for it in items):        # the second batch of the first call: held on "the GPU"
+            assert gate.wait(10)
+
+    for barrier_next in (False, True):
+        gate.clear()
+        w = _fake_worker(run_pass)
+        pool = _pool_with(w)
+        try:
+            held = _Held(pool)
+            first = [pool.submit_job(minipool.GenerationJob(req=_req(i))) for i in range(16)]            # drained as 8 + 8
+            nxt = pool.submit_job(minipool.ModeSwitchJob(target_mode="m") if barrier_next
+                                  else minipool.GenerationJob(req=_req(99, size="128x128")))
+            held.release()
+            [f.result(10) for f in first[1:8]]                    # the first batch is through (first[0] = the call itself)
+            time.sleep(0.3)
+            assert not nxt.done() and not first[0].done() and not first[15].done()
+            gate.set()
+            [f.result(10) for f in first]
+            nxt.result(10)
+            pool.q.join()
+        finally:
+            gate.set()
+            pool.shutdown()
