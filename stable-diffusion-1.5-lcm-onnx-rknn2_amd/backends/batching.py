@@ -48,7 +48,7 @@ class MicroBatcher:
         self.sizes = sorted(s for s in set(int(x) for x in sizes) if 1 <= s <= max(1, int(max_batch))) or [1]
         self.max_batch = self.sizes[-1]
         self.window = max(0.0, float(window_ms)) / 1e3
-        self._q: deque = deque()                    # (key, item, future, t_arrival)
+        self._q: deque = deque()                    # (key, item, future, t_arrival, burst)
         self._cv = threading.Condition()
         self._closed = False
         self.batches: List[int] = []                # sizes of the batches run so far (telemetry / tests)
@@ -56,12 +56,15 @@ class MicroBatcher:
         for t in self._threads:
             t.start()
 
-    def submit(self, key: Hashable, item) -> Future:
+    def submit(self, key: Hashable, item, burst: bool = False) -> Future:
+        """burst: the item belongs to a set that is complete (the single consumer thread of a pool drained it from the queue and
+        now blocks until it is served: nothing more can arrive meanwhile) -- what lane 0's pass leaves over goes to the other
+        lanes at once instead of waiting for lane 0's next, larger batch."""
         fut: Future = Future()
         with self._cv:
             if self._closed:
                 raise RuntimeError("MicroBatcher is closed")
-            self._q.append((key, item, fut, time.monotonic()))
+            self._q.append((key, item, fut, time.monotonic(), burst))
             self._cv.notify_all()                   # every lane re-evaluates (a single notify may wake a lane that defers)
         return fut
 
@@ -110,7 +113,7 @@ class MicroBatcher:
                 # the other lanes (each owns ~1.3 GB of workspace, its own buffers, tune and graph capture on first use)
                 self._cv.wait(0.05)
                 return True
-            if lane > 0 and len(self._q) > self.lane_max_waiting and not self._closed and self._lane0_alive():
+            if lane > 0 and len(self._q) > self.lane_max_waiting and not self._closed and self._lane0_alive() and not self._q[0][4]:
                 # high load: leave the queue to lane 0's next (larger) batch -- unless lane 0 is stuck inside one call
                 # (multi-second first-use tune / graph capture, waiting for a style re-merge): then serve.  Woken by
                 # lane 0's notify when it comes back for work, not by polling.

@@ -618,7 +618,7 @@ class HipLcmWorker:
         pending, fin = [], _finish_pool()
         try:
             items = list(fin.map(lambda j: self._prepare(j.req, key), [job] + others))
-            futs = [b.submit(key, it) for it in items]
+            futs = [b.submit(key, it, burst=True) for it in items]        # a complete set: the lanes split it at once
         except BaseException as e:                    # noqa  nothing was started: the drained jobs fail like the running one
             for j in others:
                 if not j.fut.done():
