@@ -198,7 +198,7 @@ def _pmc_traffic(kernel_name, batch):
         f"{e['WRITE_SIZE']:.0f} KB, averaged over {e['n_FETCH_SIZE']} launches of this kernel in an eager pass (separate --pmc runs)")
 
 
-def worker_leg(n_clients=16, n_requests=128, lone_requests=24):
+def worker_leg(n_clients=16, n_requests=128, lone_requests=24, keep_timing=False):
     """Through the reference's caller shape: ONE consumer thread takes jobs from a bounded queue and blocks in
     ``worker.run_job`` (backends/worker_pool.py:294-341; here tools/minipool.MiniPool, replayed against a recording of the real
     pool by the CPU tests).  Everything ``run_job`` does is inside the measurement: tokenise + CLIP encode, noise draw + H2D,
@@ -254,7 +254,8 @@ def worker_leg(n_clients=16, n_requests=128, lone_requests=24):
         nb0 = len(w._engine.batcher.batches)
         dtn, latn = closed_loop(n_clients, n_requests)
         sizes = w._engine.batcher.batches[nb0:]
-        return {"workload": f"run_job through a single-consumer pool-shaped loop (tools/minipool.py), 512x512 4 steps, PNG included; "
+        extra = {"timing": list(w._engine.timing or [])} if keep_timing else {}
+        return {**extra, "workload": f"run_job through a single-consumer pool-shaped loop (tools/minipool.py), 512x512 4 steps, PNG included; "
                             f"synthetic weights; {n_clients} closed-loop clients / 1 client",
                 "images_per_s": round(n_requests / dtn, 2), "clients": n_clients, "requests": n_requests,
                 "latency_p50_ms": round(statistics.median(latn) * 1e3, 2), "latency_p95_ms": round(latn[int(0.95 * (len(latn) - 1))] * 1e3, 2),

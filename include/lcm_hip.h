@@ -316,6 +316,14 @@ int lcm_debug_spin(int usec, void* stream);
  * memory of >= 16 + workgroups * 128 bytes (word 1 reads 1 afterwards if a spin gave up).  Never on the product path. */
 int lcm_debug_grid_barrier(int workgroups, int n_barriers, void* state, void* stream);
 
+/* ---- RGB8 -> PNG on the host (no GPU work): the ``img.save(buf, format="PNG")`` that closes run_job
+ * (backends/cuda_worker.py:234-239).  rgb = `height` scanlines of `width` RGB8 pixels `pitch` bytes apart; the image is cut into
+ * `stripes` deflate segments (dynamic Huffman over literals + distance-1 runs, filter "Up") compressed in parallel; the bytes
+ * written depend on (image, stripes) only.  out must hold lcm_png_bound(width, height, stripes) bytes. */
+long long lcm_png_bound(int width, int height, int stripes);
+int lcm_png_encode_rgb8(const void* rgb, int width, int height, long long pitch, int stripes, void* out, long long out_cap,
+                        long long* out_len);
+
 /* ---- AutoencoderKL.tiled_decode glue (vae.enable_tiling(), backends/cuda_worker.py:91): decoded tiles are fp32
  * pixel-major [B,h,w,3].  blend: vertical=1 -> b[y] = a[ah-extent+y]*(1-y/extent) + b[y]*(y/extent) for y < extent (aw == bw);
  * vertical=0 -> the same along x (ah == bh).  place_tile: crop [0:ch, 0:cw] of a tile into the RGB8 image at (oy, ox) with

@@ -83,19 +83,35 @@ def _deflate_stripe(args):
 def encode_png(rgb) -> bytes:
     """uint8 [H,W,3] -> PNG file bytes (the reference's ``img.save(buf, format="PNG")``, cuda_worker.py:234-239).
 
-    With the sampler at ~21 ms the PIL encoder (40-70 ms for 512x512) would dominate run_job, so the file is written
-    directly: scanline filter 2 ("Up", one vectorised numpy subtraction) + zlib level LCM_PNG_COMPRESS (default 1) in a
-    single IDAT -- lossless and deterministic.  The deflate stream is produced by LCM_PNG_THREADS (default 8; round 4: a lone
-    caller's run_job 26.0 -> 24.4 ms against 4) threads,
-    pigz-style: the filtered scanlines are cut into stripes, each stripe is a raw-deflate segment ending on a full flush
-    (byte-aligned, no back-references across the cut), the segments are concatenated behind one zlib header and closed
-    with the Adler-32 of the whole image -- one valid zlib stream, 3 ms instead of 16 for 512x512 (zlib releases the GIL).
-    The bytes depend on the thread count (not on timing).  LCM_PNG_ENCODER=pil restores the PIL path."""
-    if os.environ.get("LCM_PNG_ENCODER", "").lower() == "pil":
+    With the sampler at ~20 ms the PIL encoder (40-70 ms for 512x512) would dominate run_job, so the file is written by the
+    library's own writer (csrc/png.cpp, ``lcm_png_encode_rgb8``): scanline filter "Up", one dynamic-Huffman deflate block per
+    stripe over literals and distance-1 runs, LCM_PNG_THREADS stripes (default 8) compressed in parallel, Adler-32 / CRC-32
+    combined from the stripes -- lossless, deterministic (the bytes depend on the image and the stripe count, not on timing),
+    0.4 ms for 512x512 where zlib level 1 on 8 threads took 3 ms and PIL 40-70.
+    LCM_PNG_ENCODER=zlib: the round-3 writer (numpy filter + zlib level LCM_PNG_COMPRESS on a Python thread pool, pigz-style
+    stripes); =pil: PIL."""
+    enc = os.environ.get("LCM_PNG_ENCODER", "").lower()
+    if enc == "pil":
         from PIL import Image
         buf = io.BytesIO()
         Image.fromarray(rgb).save(buf, format="PNG", compress_level=int(os.environ.get("LCM_PNG_COMPRESS", "6")))
         return buf.getvalue()
+    if enc != "zlib":
+        import ctypes
+        from .. import lib as _lib
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+        h, w, c = rgb.shape
+        if c != 3:
+            raise ValueError(f"encode_png expects RGB, got {c} channels")
+        L = _lib.load()
+        nthr = max(1, int(os.environ.get("LCM_PNG_THREADS", "8")))
+        stripes = min(nthr, max(1, h // 64))                   # stripes of at least 64 scanlines
+        cap = int(L.lcm_png_bound(w, h, stripes))
+        out = np.empty(cap, np.uint8)
+        n = ctypes.c_longlong(0)
+        _lib.check(L.lcm_png_encode_rgb8(rgb.ctypes.data, w, h, w * 3, stripes, out.ctypes.data, cap, ctypes.byref(n)),
+                   "lcm_png_encode_rgb8")
+        return out[:n.value].tobytes()
     rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
     h, w, c = rgb.shape
     if c != 3:
@@ -590,6 +606,12 @@ class HipLcmWorker:
         deadline = _t.perf_counter() + win
         while q.qsize() < want(k) and _t.perf_counter() < deadline:
             _t.sleep(0.0003)
+        # ... and one more than last time, briefly: the previous call's OWN caller gets its result last (the pool resolves that
+        # future after run_job returns, backends/worker_pool.py:330-332) and re-submits a thread wake-up later -- taken without
+        # it, its job waits a whole pass and then leads the next call, again one short: a stable state of 15 + 1 instead of 16
+        deadline = min(deadline, _t.perf_counter() + 0.0015)
+        while q.qsize() < want(k + 1) and _t.perf_counter() < deadline:
+            _t.sleep(0.0002)
 
     def run_job(self, job) -> Tuple[bytes, int]:
         eng = self._engine
@@ -600,6 +622,7 @@ class HipLcmWorker:
         b = eng.batcher
         limit = b.max_batch * max(1, b.lanes) - 1
         import time as _t
+        t_in = _t.perf_counter()
         self._gather_wait(q, lambda k: min(k, limit))
         t_call = _t.perf_counter()
         if q.empty():
@@ -618,6 +641,7 @@ class HipLcmWorker:
         pending, fin = [], _finish_pool()
         try:
             items = list(fin.map(lambda j: self._prepare(j.req, key), [job] + others))
+            t_prep = _t.perf_counter()
             futs = [b.submit(key, it, burst=True) for it in items]        # a complete set: the lanes split it at once
         except BaseException as e:                    # noqa  nothing was started: the drained jobs fail like the running one
             for j in others:
@@ -635,7 +659,11 @@ class HipLcmWorker:
             f.add_done_callback(_cb)
         try:
             rgb, _ = futs[0].result()
-            return encode_png(rgb), items[0][1]
+            t_gpu = _t.perf_counter()
+            png = encode_png(rgb)
+            if getattr(eng, "timing", None) is not None:      # LCM_WORKER_TIMING=1: ("call", jobs, gather s, drain + prepare s, pass s, PNG s)
+                eng.timing.append(("call", len(items), t_call - t_in, t_prep - t_call, t_gpu - t_prep, _t.perf_counter() - t_gpu))
+            return png, items[0][1]
         finally:
             # return to the pool's loop only when every pass this call started has left the GPU (a mode switch may be next in
             # the queue); the drained jobs' PNGs may still be deflating on the finisher threads -- no GPU state involved.

@@ -53,6 +53,7 @@ _SIGS = {
     "lcm_timestep_embedding_steps": [_vp, _i, _vp, _i, _i, _vp],
     "lcm_scheduler_step": [_vp, _vp, _f, _vp, _vp, C.POINTER(C.c_float), _i, _i, _i, _i, _vp],
     "lcm_latents_pool8": [_vp, _vp, _i, _i, _i, _vp],
+    "lcm_png_encode_rgb8": [_vp, _i, _i, C.c_longlong, _i, _vp, C.c_longlong, C.POINTER(C.c_longlong)],
     "lcm_stream_create": [C.POINTER(_vp)],
     "lcm_stream_destroy": [_vp],
     "lcm_graph_begin": [_vp],
@@ -90,7 +91,7 @@ _SIGS = {
     "lcm_groupnorm_affine_f16": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp],
     "lcm_device_info": [_i, C.c_char_p, _i, C.POINTER(_i), C.POINTER(C.c_uint64)],
 }
-EXPORTS = tuple(sorted(list(_SIGS) + ["lcm_last_error", "lcm_version", "lcm_groupnorm_ws_bytes", "lcm_stats_bytes"]))
+EXPORTS = tuple(sorted(list(_SIGS) + ["lcm_last_error", "lcm_version", "lcm_groupnorm_ws_bytes", "lcm_stats_bytes", "lcm_png_bound"]))
 
 _lib = None
 
@@ -117,6 +118,8 @@ def load():
     lib.lcm_groupnorm_ws_bytes.restype = _i64
     lib.lcm_groupnorm_ws_bytes.argtypes = [_i, _i, _i, _i]
     lib.lcm_stats_bytes.restype = _i64
+    lib.lcm_png_bound.restype = C.c_longlong
+    lib.lcm_png_bound.argtypes = [_i, _i, _i]
     lib.lcm_stats_bytes.argtypes = [_i, _i, _i]
     _install_plans(lib)
     _lib = lib

@@ -229,6 +229,60 @@ def test_png_parallel_deflate_is_one_valid_zlib_stream():
             os.environ["LCM_PNG_THREADS"] = old
 
 
+def test_png_writer_of_the_library_handles_every_block_form():
+    """csrc/png.cpp through the C ABI: noise (stored blocks: Huffman would not pay), flat colour (distance-1 runs), vertical
+    gradients (distance-3 repeats), sparse symbols (code lengths limited to 15 / 7 bits), 1-pixel and odd-sized images, a
+    pitch wider than the row; every file must inflate strictly (Adler-32) and decode to the input; a short output buffer is
+    refused before anything is written; the round-3 zlib writer stays selectable."""
+    import ctypes, io, struct, zlib
+    from PIL import Image
+    from sdlcm_amd import lib
+    from sdlcm_amd.backends.hip_worker import encode_png
+    L = lib.load()
+    rs = np.random.RandomState(2)
+    yy, xx = np.mgrid[0:200, 0:150]
+    skew = np.zeros((200, 150, 3), np.uint8)
+    skew[rs.rand(200, 150, 3) < 0.001] = rs.randint(1, 256)          # one dominant symbol, a few rare ones
+    ramp = (rs.geometric(0.5, size=(200, 150, 3)).clip(0, 40) * 6).astype(np.uint8)      # frequencies falling by powers of two
+    cases = {"noise": rs.randint(0, 256, size=(200, 150, 3), dtype=np.uint8),
+             "flat": np.full((200, 150, 3), 77, np.uint8),
+             "vgrad": np.stack([yy, yy * 2, yy * 3], -1).astype(np.uint8),
+             "hgrad": np.stack([xx, xx * 2, xx // 2], -1).astype(np.uint8),
+             "skew": skew, "ramp": ramp,
+             "1x1": rs.randint(0, 256, size=(1, 1, 3), dtype=np.uint8),
+             "3x2": rs.randint(0, 256, size=(3, 2, 3), dtype=np.uint8)}
+    for name, img in cases.items():
+        for stripes in (1, 3):
+            h, w, _ = img.shape
+            cap = L.lcm_png_bound(w, h, stripes)
+            out = np.empty(cap, np.uint8)
+            n = ctypes.c_longlong(0)
+            assert L.lcm_png_encode_rgb8(img.ctypes.data, w, h, w * 3, stripes, out.ctypes.data, cap, ctypes.byref(n)) == 0, name
+            a = out[:n.value].tobytes()
+            Image.open(io.BytesIO(a)).verify()
+            assert np.array_equal(np.asarray(Image.open(io.BytesIO(a))), img), name
+            ln = struct.unpack(">I", a[33:37])[0]
+            raw = zlib.decompress(a[41:41 + ln])
+            assert len(raw) == h * (1 + w * 3), name
+            assert n.value <= cap
+    assert len(encode_png(cases["flat"])) < 1000 and len(encode_png(cases["vgrad"])) < 1500     # the matches are found
+    # a pitch wider than the row: a view into a larger image
+    big = rs.randint(0, 256, size=(96, 128, 3), dtype=np.uint8)
+    view = big[:, 16:80]
+    out = np.empty(L.lcm_png_bound(64, 96, 1), np.uint8)
+    n = ctypes.c_longlong(0)
+    assert L.lcm_png_encode_rgb8(view.ctypes.data, 64, 96, 128 * 3, 1, out.ctypes.data, out.size, ctypes.byref(n)) == 0
+    assert np.array_equal(np.asarray(Image.open(io.BytesIO(out[:n.value].tobytes()))), view)
+    assert L.lcm_png_encode_rgb8(view.ctypes.data, 64, 96, 128 * 3, 1, out.ctypes.data, 1000, ctypes.byref(n)) != 0
+    assert b"output buffer" in L.lcm_last_error()
+    assert L.lcm_png_encode_rgb8(view.ctypes.data, 64, 96, 100, 1, out.ctypes.data, out.size, ctypes.byref(n)) != 0       # pitch < row
+    os.environ["LCM_PNG_ENCODER"] = "zlib"
+    try:
+        assert np.array_equal(np.asarray(Image.open(io.BytesIO(encode_png(big)))), big)
+    finally:
+        del os.environ["LCM_PNG_ENCODER"]
+
+
 def test_bpe_tokenizer_id_contract(tmp_path):
     """_BpeTokenizer against a vocabulary the test writes itself: BOS + BPE ids + EOS, padding to 77 with the directory's
     own pad id (SD1.5 / first SDXL tokenizer: EOS; second SDXL tokenizer: id 0), truncation to 77 keeping EOS last, int32 --

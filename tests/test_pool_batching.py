@@ -306,3 +306,36 @@ def test_run_job_returns_only_when_every_pass_it_started_has_left_the_gpu():
         finally:
             gate.set()
             pool.shutdown()
+
+
+def test_burst_tail_is_padded_to_a_plan_size_when_that_is_cheaper():
+    """A complete set of 15 (8 on lane 0) leaves 7: one pass of 8 with the last item repeated instead of 4 + 2 + 1 one after
+    the other; the repeated item's result is dropped, every real item gets its own.  5 stays 4 + 1; without the burst flag
+    nothing is padded."""
+    import threading
+    from sdlcm_amd.backends.batching import MicroBatcher
+    gate, seen = threading.Event(), []
+
+    def run(key, items, lane=0):
+        seen.append((lane, list(items)))
+        if lane == 0:
+            gate.wait(10)
+        return [i * 10 for i in items]
+    mb = MicroBatcher(run, max_batch=8, lanes=2)
+    try:
+        futs = [mb.submit("k", i, burst=True) for i in range(15)]
+        res = [f.result(timeout=10) for f in futs[8:]]
+        assert res == [i * 10 for i in range(8, 15)]
+        lane1 = [it for ln, it in seen if ln == 1]
+        assert lane1 == [[8, 9, 10, 11, 12, 13, 14, 14]]
+        gate.set()
+        assert [f.result(timeout=10) for f in futs[:8]] == [i * 10 for i in range(8)]
+        assert sorted(mb.batches) == [7, 8]
+    finally:
+        gate.set()
+        mb.close()
+    one = MicroBatcher(lambda key, items: [i + 1 for i in items], max_batch=8, lanes=1)
+    try:
+        assert one._split_cost(5) < one._cost(8) and one._split_cost(7) > one._cost(8) and one._split_cost(3) > one._cost(4)
+    finally:
+        one.close()
