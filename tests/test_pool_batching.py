@@ -339,3 +339,50 @@ def test_burst_tail_is_padded_to_a_plan_size_when_that_is_cheaper():
         assert one._split_cost(5) < one._cost(8) and one._split_cost(7) > one._cost(8) and one._split_cost(3) > one._cost(4)
     finally:
         one.close()
+
+
+def test_dispatcher_stress_every_future_resolves_once_with_its_own_result():
+    """Random mix of open arrivals and complete (burst) sets over three keys and two lanes, passes of random length, a failing
+    key: every future resolves exactly once, with its own item's result or the pass's error; batch sizes stay plan sizes;
+    repeated (padding) items never reach a caller."""
+    import random
+    import threading
+    import time as _t
+    from sdlcm_amd.backends.batching import MicroBatcher
+    rng = random.Random(7)
+    seen_sizes, lock = [], threading.Lock()
+
+    def run(key, items, lane=0):
+        with lock:
+            seen_sizes.append(len(items))
+        _t.sleep(rng.random() * 0.004)
+        if key == "bad":
+            raise ValueError("pass failed")
+        return [(key, i) for i in items]
+    mb = MicroBatcher(run, max_batch=8, lanes=2)
+    futs = []
+    try:
+        n = 0
+        for rnd in range(60):
+            key = rng.choice(["a", "a", "b", "bad"])
+            if rng.random() < 0.5:
+                k = rng.randint(1, 16)
+                futs += [(key, n + j, mb.submit(key, n + j, burst=True)) for j in range(k)]
+            else:
+                k = rng.randint(1, 5)
+                for j in range(k):
+                    futs.append((key, n + j, mb.submit(key, n + j)))
+                    _t.sleep(rng.random() * 0.001)
+            n += k
+            if rng.random() < 0.3:
+                _t.sleep(rng.random() * 0.01)
+        for key, i, f in futs:
+            if key == "bad":
+                with pytest.raises(ValueError, match="pass failed"):
+                    f.result(timeout=30)
+            else:
+                assert f.result(timeout=30) == (key, i)
+        assert set(seen_sizes) <= {1, 2, 4, 8}
+        assert sum(mb.batches) == sum(1 for key, _, _ in futs if key != "bad")
+    finally:
+        mb.close()
