@@ -172,6 +172,37 @@ def test_single_consumer_pool_drains_queue_into_one_pass(worker):
         pool.shutdown()
 
 
+def test_drained_set_of_fifteen_runs_as_eight_plus_a_padded_eight(worker):
+    """A complete set that is not a sum of plan sizes: 15 queued requests -> lane 0 takes 8, the other lane takes the remaining
+    7 as ONE batch-8 pass with the last request repeated (cheaper than 4 + 2 + 1 one after the other); every future gets the
+    bytes of its solo run, the repeated item's result goes nowhere."""
+    import sys, threading
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from tools import minipool
+    if worker._engine.n_lanes < 2:
+        pytest.skip("needs two lanes")
+    solo = {s: worker.run_job(MockJob(MockGenerateRequest(prompt=f"p {s}", size="128x128", num_inference_steps=2, seed=s))) for s in range(15)}
+    pool = minipool.MiniPool(lambda worker_id: worker, {"m": "synthetic"}, "m")
+    worker.bind_queue(pool.q)
+    try:
+        gate, inside = threading.Event(), threading.Event()
+        hold = pool.submit_job(minipool.CustomJob(handler=lambda: (inside.set(), gate.wait(30))))
+        assert inside.wait(30)
+        n0 = len(worker._engine.batcher.batches)
+        futs = [pool.submit_job(minipool.GenerationJob(req=MockGenerateRequest(prompt=f"p {s}", size="128x128", num_inference_steps=2, seed=s)))
+                for s in range(15)]
+        gate.set()
+        hold.result(60)
+        res = [f.result(600) for f in futs]
+        pool.q.join()
+        assert res == [solo[s] for s in range(15)]
+        assert sorted(worker._engine.batcher.batches[n0:]) == [7, 8]                # real items per pass: 8, and 7 in a pass of 8
+    finally:
+        worker.bind_queue(None)
+        pool._worker = None
+        pool.shutdown()
+
+
 def test_sdxl_worker_contract():
     """DiffusersSDXLCudaWorker's behavioural contract (tests/test_sdxl_worker.py in the reference) on the SDXL-family HIP
     worker with synthetic full-size SDXL weights: (bytes,int), PNG, seed echo, determinism, 512-byte latents, CFG path."""
