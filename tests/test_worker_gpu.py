@@ -203,6 +203,54 @@ def test_drained_set_of_fifteen_runs_as_eight_plus_a_padded_eight(worker):
         pool.shutdown()
 
 
+def test_mixed_load_behind_the_pool_keeps_every_request_its_own_bytes(worker):
+    """12 closed-loop clients, 360 requests over three (size, steps) keys and 40 distinct (prompt, seed) pairs, through the
+    single-consumer pool: whatever pass a request lands in (batch 1 ... 8, padded or not, either lane, after any other key),
+    its PNG is byte-identical to every other time the same request was served -- and to its solo run."""
+    import random, sys, threading
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from tools import minipool
+    keys = [("256x256", 2), ("128x128", 2), ("256x256", 3)]
+
+    def req(i):
+        size, steps = keys[i % 3]
+        return MockGenerateRequest(prompt=f"soak {i % 40}", size=size, num_inference_steps=steps, seed=500 + i % 40)
+    solo = {i: worker.run_job(MockJob(req(i))) for i in range(40)}
+    pool = minipool.MiniPool(lambda worker_id: worker, {"m": "synthetic"}, "m", queue_max=64)
+    worker.bind_queue(pool.q)
+    errors, lock, nxt = [], threading.Lock(), [0]
+    rng = random.Random(3)
+    order = [rng.randrange(40) for _ in range(360)]
+    n0 = len(worker._engine.batcher.batches)
+
+    def client():
+        while True:
+            with lock:
+                k = nxt[0]
+                nxt[0] += 1
+            if k >= len(order):
+                return
+            i = order[k]
+            try:
+                got = pool.submit_job(minipool.GenerationJob(req=req(i))).result(timeout=600)
+                if got != solo[i]:
+                    errors.append(f"request {i} (#{k}) differs from its solo run")
+            except Exception as e:      # noqa
+                errors.append(f"request {i} (#{k}): {e!r}")
+    try:
+        th = [threading.Thread(target=client) for _ in range(12)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        pool.q.join()
+        assert not errors, errors[:5]
+        sizes = worker._engine.batcher.batches[n0:]
+        assert sum(sizes) == 360 and max(sizes) > 1, sizes[:20]          # batching did engage
+    finally:
+        worker.bind_queue(None)
+        pool._worker = None
+        pool.shutdown()
+
+
 def test_sdxl_worker_contract():
     """DiffusersSDXLCudaWorker's behavioural contract (tests/test_sdxl_worker.py in the reference) on the SDXL-family HIP
     worker with synthetic full-size SDXL weights: (bytes,int), PNG, seed echo, determinism, 512-byte latents, CFG path."""
