@@ -27,7 +27,7 @@ UPS_PHASES = os.environ.get("LCM_UPS_PHASES", "1") != "0"
 # the staged element is transformed once per n-tile of the conv, so few n-tiles (<= 4 with the 160-wide tile, <= 3 with
 # 128) and a tensor too large for the Infinity Cache, so that the separate pass really is HBM time (in situ the apply pass
 # reads what the producer just wrote: below ~64 MB it is served from MALL and fusing gains nothing; measured +1.5 % at
-# batch 8 and +0.2 % at batch 1 with the VAE's 512^2 / 256^2 levels fused; tools/gn_fuse_bench.py has the cold numbers)
+# batch 8 and +0.2 % at batch 1 with the VAE's 512^2 / 256^2 levels fused; tools/gn_fuse_ab.py re-measures it per shape: profiles/r04_gn_fuse_ab.txt)
 # LayerNorm folded into the GEMM that consumes it (norm1 -> q|k|v, norm2 -> attn2.to_q, norm3 -> GEGLU proj): 192 launches
 # fewer per 512x512 4-step pass, no LayerNorm output in HBM (ops.gemm_ln / lcm_gemm_ln_f16)
 LN_FOLD = os.environ.get("LCM_LN_FOLD", "1") != "0"
